@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the importable parts of the reference and write golden vectors.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's Python modules that import cleanly here,
+feeds them seeded synthetic inputs, checks that ``oracle/seedvr2_ref`` reproduces them,
+and commits the input/output vectors as small fixtures under ``tests/golden/`` so that
+the CPU test-suite can re-check the oracle (and the product's host logic) without the
+reference.  Fixtures are data only (inputs + expected outputs).
+
+Name-only stubs (no arithmetic) are installed for ``omegaconf``, ``diffusers`` and
+``rotary_embedding_torch`` so that modules which merely mention those names can be
+imported; anything that would need their arithmetic stays "parity unpinned".
+
+usage:  python oracle/pin_against_reference.py
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never write into /root/reference
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+from safetensors.torch import save_file
+
+from seedvr2_ref import dit as odit
+from seedvr2_ref import windows as owin
+
+
+def _install_name_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Name:  # placeholder type, never instantiated on the paths we run
+        pass
+
+    mod("omegaconf", DictConfig=type("DictConfig", (dict,), {}), ListConfig=type("ListConfig", (list,), {}),
+        OmegaConf=_Name)
+    mod("diffusers")
+    mod("diffusers.models")
+    mod("diffusers.models.normalization", RMSNorm=type("RMSNorm", (torch.nn.Module,), {}))
+    mod("rotary_embedding_torch", RotaryEmbedding=_Name, apply_rotary_emb=None)
+
+
+def check(name, a, b, tol=0.0):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ok = a.shape == b.shape and err <= tol
+    print(f"  [{'ok' if ok else 'FAIL'}] {name}: shape {tuple(a.shape)} max|d|={err:.3e} (tol {tol:g})")
+    if not ok:
+        raise SystemExit(f"oracle disagrees with the reference on {name}")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    _install_name_stubs()
+    torch.manual_seed(0)
+    tensors = {}
+    meta = {}
+
+    # ------------------------------------------------------------------ G1 windows
+    from src.models.dit_3b import window as rwin
+    grids = [(1, 32, 32), (3, 68, 120), (5, 135, 240), (6, 135, 240), (17, 135, 240), (2, 24, 40), (3, 20, 36),
+             (1, 16, 16), (5, 34, 60), (9, 45, 80), (33, 45, 80)]
+    g1 = {}
+    for g in grids:
+        for meth, ofn in ((owin.REGULAR, owin.regular_windows), (owin.SHIFTED, owin.shifted_windows)):
+            ref = [(s[0].start, s[0].stop, s[1].start, s[1].stop, s[2].start, s[2].stop)
+                   for s in rwin.get_window_op(meth)(g, (4, 3, 3))]
+            mine = ofn(g, (4, 3, 3))
+            assert [tuple(x) for x in mine] == ref, (g, meth)
+            g1[f"{g[0]}x{g[1]}x{g[2]}|{meth}"] = ref
+    print(f"  [ok] G1 window boxes: {len(g1)} (grid, method) cases identical")
+    meta["G1_windows"] = g1
+
+    # ------------------------------------------------------------------ G2 na index helpers
+    from src.models.dit_3b import na as rna
+    g2 = {}
+    for g in [(2, 24, 40), (3, 20, 36), (1, 16, 16)]:
+        for meth in (owin.REGULAR, owin.SHIFTED):
+            op = rwin.get_window_op(meth)
+            shape = torch.tensor([list(g)])
+
+            def make_window(x, op=op):
+                t, h, w, _ = x.shape
+                return [x[st, sh, sw] for (st, sh, sw) in op((t, h, w), (4, 3, 3))]
+
+            part, rev, wshape, wcount = rna.window_idx(shape, make_window)
+            L = g[0] * g[1] * g[2]
+            ids = torch.arange(L)[:, None].float()
+            tgt = part(ids)[:, 0].long()
+            idx, lens, shapes = owin.window_token_index(g, owin.windows_for(meth, g))
+            check(f"G2 window_idx {g} {meth}", tgt, idx)
+            check(f"G2 window shapes {g} {meth}", wshape, shapes)
+            assert int(wcount[0]) == len(lens)
+            check("G2 window reverse", rev(part(ids)), ids)
+            g2[f"{g[0]}x{g[1]}x{g[2]}|{meth}"] = {"idx_sum": int(tgt.sum()), "idx_head": tgt[:64].tolist(),
+                                                  "lens": lens.tolist()}
+    # repeat_concat_idx + text mean (na.py:320-424)
+    vid_len = torch.tensor([3, 2, 4])
+    txt_len = torch.tensor([2])
+    cat, uncat = rna.repeat_concat_idx(vid_len, txt_len, torch.tensor([3]))
+    vid = torch.arange(9).float()[:, None]
+    txt = torch.tensor([100.0, 200.0])[:, None]
+    allv = cat(vid, txt)
+    check("G2 repeat_concat order", allv[:, 0], [0, 1, 2, 100, 200, 3, 4, 100, 200, 5, 6, 7, 8, 100, 200])
+    noisy = allv + torch.arange(allv.shape[0]).float()[:, None] * 0.5
+    v_out, t_out = uncat(noisy)
+    check("G2 unconcat vid", v_out[:, 0], [0, 1.5, 3, 5.5, 7, 9.5, 11, 12.5, 14])
+    check("G2 unconcat txt mean", t_out[:, 0], [100 + (1.5 + 3.5 + 6.5) / 3, 200 + (2 + 4 + 7) / 3])
+    meta["G2_index"] = g2
+
+    # ------------------------------------------------------------------ G3 varlen attention
+    from src.models.dit_3b.attention import pytorch_varlen_attention
+    lens = [37, 58 + 13, 128, 5]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    q = torch.randn(sum(lens), 2, 128)
+    k = torch.randn(sum(lens), 2, 128)
+    v = torch.randn(sum(lens), 2, 128)
+    ref = pytorch_varlen_attention(q, k, v, cu, cu)
+    mine = []
+    off = 0
+    for n in lens:
+        qs, ks, vs = (t[off:off + n].permute(1, 0, 2) for t in (q, k, v))
+        pr = torch.softmax((qs @ ks.transpose(1, 2)) / 128 ** 0.5, dim=-1)
+        mine.append((pr @ vs).permute(1, 0, 2))
+        off += n
+    check("G3 varlen attention (fp32)", torch.cat(mine), ref, 2e-6)
+    tensors.update({"G3.q": q, "G3.k": k, "G3.v": v, "G3.cu": cu, "G3.out": ref})
+
+    # ------------------------------------------------------------------ G4 AdaSingle + cache collision
+    from src.common.cache import Cache
+    from src.models.dit_3b.modulation import AdaSingle
+    dim = 32
+    emb = torch.randn(1, 6 * dim)
+    blk = AdaSingle(dim, 6 * dim, layers=["attn", "mlp"])
+    outada = AdaSingle(dim, 6 * dim, layers=["out"], modes=["in"])
+    hid = torch.randn(7, dim)
+    cache = Cache()
+    hl = torch.tensor([7])
+    r_in = blk(hid.clone(), emb, layer="attn", mode="in", cache=cache, branch_tag="vid", hid_len=hl)
+    r_mlp = blk(hid.clone(), emb, layer="mlp", mode="in", cache=cache, branch_tag="vid", hid_len=hl)
+    r_gate = blk(hid.clone(), emb, layer="mlp", mode="out", cache=cache, branch_tag="vid", hid_len=hl)
+    r_out = outada(hid.clone(), emb, layer="out", mode="in", cache=cache, branch_tag="vid", hid_len=hl)
+    sh0, sc0, ga0 = odit.ada_slices(emb[0], 0)
+    sh1, sc1, ga1 = odit.ada_slices(emb[0], 1)
+    check("G4 ada attn in", hid * (sc0 + blk.attn_scale) + (sh0 + blk.attn_shift), r_in.detach(), 1e-6)
+    check("G4 ada mlp in", hid * (sc1 + blk.mlp_scale) + (sh1 + blk.mlp_shift), r_mlp.detach(), 1e-6)
+    check("G4 ada mlp gate", hid * (ga1 + blk.mlp_gate), r_gate.detach(), 1e-6)
+    check("G4 vid_out_ada (cache collision -> attn slice)", hid * (sc0 + outada.out_scale) + (sh0 + outada.out_shift),
+          r_out.detach(), 1e-6)
+    tensors.update({"G4.emb": emb, "G4.hid": hid, "G4.attn_shift": blk.attn_shift.detach(),
+                    "G4.attn_scale": blk.attn_scale.detach(), "G4.mlp_gate": blk.mlp_gate.detach(),
+                    "G4.out_shift": outada.out_shift.detach(), "G4.out_scale": outada.out_scale.detach(),
+                    "G4.r_in": r_in.detach(), "G4.r_gate": r_gate.detach(), "G4.r_out": r_out.detach()})
+
+    # ------------------------------------------------------------------ G6 patch in/out, G7 rmsnorm
+    from src.models.dit_3b.patch.patch_v1 import NaPatchIn, NaPatchOut
+    pin = NaPatchIn(in_channels=5, patch_size=(1, 2, 2), dim=16)
+    pout = NaPatchOut(out_channels=3, patch_size=(1, 2, 2), dim=16)
+    shp = torch.tensor([[3, 4, 6]])
+    xin = torch.randn(3 * 4 * 6, 5)
+    c = Cache()
+    yref, gshape = pin(xin, shp, c)
+    ymine = torch.nn.functional.linear(odit.patch_in(xin, (3, 4, 6), (1, 2, 2)), pin.proj.weight, pin.proj.bias)
+    check("G6 NaPatchIn", ymine.detach(), yref.detach(), 1e-6)
+    zref, _ = pout(yref, gshape, c)
+    zmine = odit.patch_out(torch.nn.functional.linear(yref, pout.proj.weight, pout.proj.bias), (3, 2, 3), (1, 2, 2), 3)
+    check("G6 NaPatchOut", zmine.detach(), zref.detach(), 1e-6)
+    tensors.update({"G6.x": xin, "G6.win": pin.proj.weight.detach(), "G6.bin": pin.proj.bias.detach(),
+                    "G6.y": yref.detach(), "G6.wout": pout.proj.weight.detach(), "G6.bout": pout.proj.bias.detach(),
+                    "G6.z": zref.detach()})
+
+    from src.models.dit_3b.normalization import CustomRMSNorm
+    rn = CustomRMSNorm(128, eps=1e-5, elementwise_affine=True)
+    with torch.no_grad():
+        rn.weight.copy_(1 + 0.1 * torch.randn(128))
+    xr = torch.randn(9, 4, 128)
+    check("G7 CustomRMSNorm fp32", odit.rms_norm(xr, 1e-5, rn.weight.detach()), rn(xr).detach(), 1e-6)
+    check("G7 CustomRMSNorm bf16", odit.rms_norm(xr.bfloat16(), 1e-5, rn.weight.detach().bfloat16()).float(),
+          rn.bfloat16()(xr.bfloat16()).detach().float(), 0.0)
+    rn.float()
+    tensors.update({"G7.x": xr, "G7.w": rn.weight.detach().float(), "G7.y": rn(xr).detach()})
+
+    # ------------------------------------------------------------------ G5/G8 a full transformer block (no RoPE)
+    # mmsr_block + mmattn + mlp + mm + modulation + normalization run as-is; rope_type=None because the
+    # RoPE arithmetic lives in the absent rotary_embedding_torch.
+    from src.models.dit_3b.nablocks.mmsr_block import NaMMSRTransformerBlock
+    from src.models.dit_3b.modulation import get_ada_layer
+    from src.models.dit_3b.normalization import get_norm_layer
+    for tag, shared, last, meth in (("sep", False, False, owin.REGULAR), ("shared_last", True, True, owin.SHIFTED)):
+        torch.manual_seed(7)
+        cfg = odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, num_layers=1 if last else 2,
+                             mm_layers=0 if shared else 1, mlp_multiple_of=32)
+        blk = NaMMSRTransformerBlock(
+            vid_dim=64, txt_dim=64, emb_dim=384, heads=2, head_dim=32, expand_ratio=4,
+            norm=get_norm_layer("fusedrms"), norm_eps=1e-5, ada=get_ada_layer("single"), qk_bias=False,
+            qk_norm=get_norm_layer("fusedrms"), mlp_type="swiglu", shared_weights=shared, rope_type=None,
+            rope_dim=32, is_last_layer=last, window=(4, 3, 3), window_method=meth)
+        with torch.no_grad():
+            for n_, p_ in blk.named_parameters():
+                if "norm_" in n_:
+                    p_.copy_(1 + 0.1 * torch.randn_like(p_))
+        grid = (2, 12, 20)
+        L = grid[0] * grid[1] * grid[2]
+        vid = torch.randn(L, 64)
+        txt = torch.randn(58, 64)
+        emb = torch.randn(1, 384)
+        with torch.no_grad():
+            v_ref, t_ref, _, _ = blk(vid.clone(), txt.clone(), torch.tensor([list(grid)]), torch.tensor([[58]]),
+                                     emb, Cache())
+        # same block through the oracle's forward() by wrapping it as a 1-layer model
+        p = {f"blocks.0.{k}": v.detach() for k, v in blk.state_dict().items()}
+        v_mine, t_mine, _ = odit.block(p, cfg, 0, vid, txt, emb[0], grid, torch.float32, "none", method=meth)
+        check(f"G8 transformer block [{tag}] vid", v_mine, v_ref, 2e-5)
+        if not last:
+            check(f"G8 transformer block [{tag}] txt", t_mine, t_ref, 2e-5)
+        for k, v in p.items():
+            tensors[f"G8.{tag}.p.{k}"] = v.contiguous()
+        tensors.update({f"G8.{tag}.vid": vid, f"G8.{tag}.txt": txt, f"G8.{tag}.emb": emb,
+                        f"G8.{tag}.vid_out": v_ref, f"G8.{tag}.txt_out": t_ref})
+        meta[f"G8.{tag}"] = {"grid": list(grid), "method": meth, "shared": shared, "last": last,
+                             "cfg": {"vid_dim": 64, "heads": 2, "head_dim": 32, "num_layers": cfg.num_layers,
+                                     "mm_layers": cfg.mm_layers, "mlp_multiple_of": 32}}
+
+    # ------------------------------------------------------------------ G9 one-step Euler endpoint
+    from src.common.diffusion.schedules.lerp import LinearInterpolationSchedule
+    from src.common.diffusion.samplers.euler import EulerSampler
+    from src.common.diffusion.timesteps.sampling.trailing import UniformTrailingSamplingTimesteps
+    from src.common.diffusion.types import PredictionType
+    sched = LinearInterpolationSchedule(T=1000.0)
+    ts = UniformTrailingSamplingTimesteps(T=sched.T, steps=1)
+    smp = EulerSampler(schedule=sched, timesteps=ts, prediction_type="v_lerp")
+    x = torch.randn(11, 16)
+    seen = {}
+
+    def f(args):
+        seen["t"] = args.t.clone()
+        return 0.3 * args.x_t + 1.0
+
+    res = smp.sample(x=x, f=f)
+    check("G9 timesteps == [1000]", ts.timesteps, [1000.0])
+    check("G9 one-step endpoint x0 = x - f(x)", x - (0.3 * x + 1.0), res, 1e-6)
+    meta["G9"] = {"t_seen": float(seen["t"])}
+
+    save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
+    with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:
+        json.dump(meta, fh)
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
