@@ -1,0 +1,12 @@
+"""seedvr2_amd - MI355X-native SeedVR2 upscaler hot path behind the reference's plugin surface.
+
+Directory name follows the ComfyUI custom-node convention (hyphenated); import it through
+``__graft_entry__.load_package()`` or ComfyUI's own loader.  Submodules:
+  hip      ctypes binding of libseedvr2_hip.so (the C ABI, include/seedvr2_hip.h)
+  windows  host-side window geometry / index tables of the swin attention
+  dit      NaDiT runner on the HIP kernels
+"""
+
+from . import hip  # noqa: F401
+from . import windows  # noqa: F401
+from . import dit  # noqa: F401

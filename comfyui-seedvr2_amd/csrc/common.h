@@ -1,0 +1,52 @@
+// Shared device/host helpers for libseedvr2_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/seedvr2_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-byte direct global -> LDS copy: LDS destination is wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- host side error plumbing (thread-local message, see include/seedvr2_hip.h)
+void svr2_set_error(const char* fmt, ...);
+#define SVR2_CHECK(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            svr2_set_error(__VA_ARGS__);     \
+            return (code);                   \
+        }                                    \
+    } while (0)
+#define SVR2_LAUNCH_CHECK()                                                        \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            svr2_set_error("launch failed: %s", hipGetErrorString(e_));            \
+            return SVR2_E_LAUNCH;                                                  \
+        }                                                                          \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,376 @@
+// bf16 MFMA GEMM core for gfx950: dense / row-gathered / implicit-conv3d A operand, fused epilogues.
+//
+// Tile: 128 x 128 x 64 per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA
+// 16x16x32 tiles, fp32 accumulators).  Both operands are K-contiguous and are staged with direct
+// global->LDS 16-byte loads (global_load_lds_dwordx4) into a 2-deep ring; the next K-tile's loads
+// are in flight while the current one is multiplied, one barrier per K-tile.  The LDS image is
+// lane-linear (that is what the DMA writes), so the bank swizzle chunk ^= (row >> 1) & 7 is applied
+// on the per-lane SOURCE address and again on the ds_read_b128 address (conflict-free).
+// For the implicit conv the A row of an output pixel is the 128-byte channel run of the input pixel
+// under the current filter tap, so the same loader serves it with a different per-row base pointer;
+// zero padding and rows past M read a zero page.  Accumulators leave through an fp32 LDS tile so
+// every epilogue works on 8 consecutive columns and stores 16 bytes per lane, whole 256-byte rows.
+#include "common.h"
+#include <stdarg.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // 64 KiB, reused as the fp32 [128][128] epilogue tile
+constexpr int GROUP_M = 8;                        // band height (in tiles) of the L2-friendly tile order
+
+enum AMode { A_DENSE = 0, A_CONV = 1 };
+
+struct ConvGeom {
+    const bf16* carry;
+    int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
+};
+
+struct KArgs {
+    const bf16* A;
+    const bf16* W;
+    bf16* C;
+    const int32_t* a_rows;
+    const float* bias;
+    const float* gate;
+    const bf16* resid;
+    const bf16* zero;
+    long long lda, ldc, ldr;
+    int M, N, K, nbm, nbn;
+    int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
+    ConvGeom cg;
+};
+
+__device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
+    // XCD-aware remap (bijective form): blocks b and b+8 share an XCD; give every XCD a contiguous
+    // run of the tile order, and order tiles in bands of GROUP_M row-tiles so that the workgroups
+    // resident on one XCD share A row-panels and W column-panels in its L2.
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_band = GROUP_M * a.nbn;
+    const int band = lin / per_band, rem = lin - band * per_band;
+    const int rows = min(GROUP_M, a.nbm - band * GROUP_M);
+    tm = band * GROUP_M + rem % rows;
+    tn = rem / rows;
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tm, tn;
+    tile_coords(a, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- loader setup: this thread moves 4 A rows and 4 W rows (16 bytes each) per K-tile.
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const char* a_ptr[4];
+    const char* w_ptr[4];
+    int a_choff[4];
+    int cy[4], cx[4], ct[4];  // conv: output pixel of each row (scaled by stride), cy < -(1<<20) => row invalid
+    const char* zero = (const char*)a.zero;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + lrow;
+        const int chunk = lpos ^ ((r >> 1) & 7);
+        a_choff[i] = chunk * 16;
+        w_ptr[i] = (const char*)(a.W + (long long)(n0 + r) * a.K) + chunk * 16;
+        const int m = m0 + r;
+        if (AMODE == A_DENSE) {
+            if (m < a.M) {
+                const long long src = a.a_rows ? (long long)a.a_rows[m] : (long long)m;
+                a_ptr[i] = (const char*)(a.A + src * a.lda) + chunk * 16;
+            } else {
+                a_ptr[i] = nullptr;
+            }
+        } else {
+            a_ptr[i] = nullptr;
+            if (m < a.M) {
+                const int x = m % a.cg.Wo, t2 = m / a.cg.Wo;
+                const int y = t2 % a.cg.Ho, t = t2 / a.cg.Ho;
+                cx[i] = x * a.cg.sw - a.cg.pad_w0;
+                cy[i] = y * a.cg.sh - a.cg.pad_h0;
+                ct[i] = t * a.cg.st;
+            } else {
+                cx[i] = 0; cy[i] = -(1 << 28); ct[i] = 0;
+            }
+        }
+    }
+    // conv tap state
+    int tap_t = 0, tap_y = 0, tap_x = 0, tap_c = 0;
+
+    auto issue = [&](int kt, int stage) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* src;
+            if (AMODE == A_DENSE) {
+                src = a_ptr[i] ? a_ptr[i] + (long long)kt * (BK * 2) : zero + lpos * 16;
+            } else {
+                const int iy = cy[i] + tap_y, ix = cx[i] + tap_x, it = ct[i] + tap_t;
+                const bool ok = (iy >= 0) & (iy < a.cg.Hi) & (ix >= 0) & (ix < a.cg.Wi);
+                const long long frame_elems = (long long)a.cg.Hi * a.cg.Wi * a.cg.Cin;
+                const char* fbase;
+                if (it < a.cg.npad)
+                    fbase = a.cg.carry ? (const char*)(a.cg.carry + (long long)it * frame_elems) : (const char*)a.A;
+                else
+                    fbase = (const char*)(a.A + (long long)(it - a.cg.npad) * frame_elems);
+                const long long off = ((long long)iy * a.cg.Wi + ix) * a.cg.Cin + tap_c;
+                src = ok ? fbase + off * 2 + a_choff[i] : zero + lpos * 16;
+            }
+            glds16(src, sA + (wave * 4 + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(w_ptr[i] + (long long)kt * (BK * 2), sB + (wave * 4 + i) * 1024);
+        if (AMODE == A_CONV) {  // advance the filter tap: K order is ((kt*kh + ky)*kw + kx)*Cin + c
+            tap_c += BK;
+            if (tap_c == a.cg.Cin) {
+                tap_c = 0;
+                if (++tap_x == a.cg.kw) {
+                    tap_x = 0;
+                    if (++tap_y == a.cg.kh) { tap_y = 0; ++tap_t; }
+                }
+            }
+        }
+    };
+
+    // ---- MFMA fragment addressing
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int swz = (frow >> 1) & 7;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; every wave is done reading stage (kt+1)&1
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* sA = smem + (kt & 1) * STAGE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+            const int chunk = ((fq + 4 * ks) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *(const bf16x8*)(sA + (wm * 64 + i * 16 + frow) * 128 + chunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[j] = *(const bf16x8*)(sB + (wn * 64 + j * 16 + frow) * 128 + chunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue through an fp32 LDS tile [128][128]
+    __syncthreads();
+    float* tile = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(wm * 64 + i * 16 + fq * 4 + r) * BN + wn * 64 + j * 16 + frow] = acc[i][j][r];
+    __syncthreads();
+
+    if (EPI == SVR2_EPI_SWIGLU) {
+        // columns [16p, 16p+8) = gate, [16p+8, 16p+16) = in  ->  output columns [8p, 8p+8)
+        for (int c = tid; c < BM * 8; c += NTHREADS) {
+            const int row = c >> 3, p = c & 7;
+            const int m = m0 + row, ncol = (n0 >> 1) + p * 8;
+            if (m >= a.M || (n0 + p * 16) >= a.N) continue;
+            const float* g = tile + row * BN + p * 16;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gv = g[e], iv = g[8 + e];
+                o[e] = f2bf(gv / (1.f + __expf(-gv)) * iv);
+            }
+            *(bf16x8*)(a.C + (long long)m * a.ldc + ncol) = o;
+        }
+        return;
+    }
+
+    for (int c = tid; c < BM * 16; c += NTHREADS) {
+        const int row = c >> 4, cc = c & 15;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if (m >= a.M || n >= a.N) continue;
+        const float* src = tile + row * BN + cc * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e];
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (n + e < a.N) ? a.bias[n + e] : 0.f;
+        }
+        long long dst;
+        if (EPI == SVR2_EPI_GATE_RES) {
+            const bf16x8 rv = *(const bf16x8*)(a.resid + (long long)m * a.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + (a.gate ? a.gate[n + e] : 1.f) * v[e];
+            dst = (long long)m * a.ldc + n;
+        } else if (EPI == SVR2_EPI_PIXSHUF3D) {
+            const int Cc = a.ps_c, tz = a.ps_tz;
+            const int qd = n / Cc, ch = n - qd * Cc;
+            const int z = qd % tz, yy = (qd / tz) & 1, xx = qd / (2 * tz);
+            const int w = m % a.ps_w, t2 = m / a.ps_w;
+            const int h = t2 % a.ps_h, f = t2 / a.ps_h;
+            int fo = f * tz + z;
+            if (a.ps_drop) {
+                if (fo == 1) continue;
+                if (fo > 1) fo -= 1;
+            }
+            dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
+        } else {
+            if (a.resid) {  // conv residual add
+                const bf16x8 rv = *(const bf16x8*)(a.resid + (long long)m * a.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+            }
+            dst = (long long)m * a.ldc + n;
+        }
+        if (n + 8 <= a.N) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            *(bf16x8*)(a.C + dst) = o;
+        } else {
+            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = f2bf(v[e]);
+        }
+    }
+}
+
+template <int AMODE, int EPI>
+int launch(const KArgs& a, hipStream_t s) {
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI>), dim3(a.nbm * a.nbn), dim3(NTHREADS), LDS_BYTES, s, a);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+}  // namespace
+
+static thread_local char g_err[512] = "";
+void svr2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* svr2_last_error(void) { return g_err; }
+extern "C" int svr2_abi_version(void) { return SVR2_ABI_VERSION; }
+
+extern "C" int svr2_device_check(int dev) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        svr2_set_error("hipGetDeviceProperties(%d) failed", dev);
+        return SVR2_E_ARCH;
+    }
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        svr2_set_error("device %d is %s, libseedvr2_hip is built for gfx950 only", dev, p.gcnArchName);
+        return SVR2_E_ARCH;
+    }
+    return p.multiProcessorCount;
+}
+
+extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
+    SVR2_CHECK(d && d->A && d->W && d->C && d->zero_page, SVR2_E_ARG, "svr2_gemm: null pointer");
+    SVR2_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->K % BK == 0, SVR2_E_SHAPE,
+               "svr2_gemm: need M,N,K > 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)d->M, (long long)d->N,
+               (long long)d->K);
+    SVR2_CHECK(d->M < (1ll << 31) - BM && d->N < (1ll << 30), SVR2_E_SHAPE, "svr2_gemm: M/N too large");
+    SVR2_CHECK(d->lda % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->W) && aligned16(d->C),
+               SVR2_E_ALIGN, "svr2_gemm: A/W/C must be 16-byte aligned with lda, ldc %% 8 == 0");
+    SVR2_CHECK(d->lda >= d->K, SVR2_E_SHAPE, "svr2_gemm: lda < K");
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)d->A; a.W = (const bf16*)d->W; a.C = (bf16*)d->C;
+    a.a_rows = d->a_rows; a.bias = d->bias; a.gate = d->gate; a.resid = (const bf16*)d->resid;
+    a.zero = (const bf16*)d->zero_page;
+    a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
+    a.nbm = (a.M + BM - 1) / BM; a.nbn = (a.N + BN - 1) / BN;
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->epilogue) {
+        case SVR2_EPI_BIAS:
+            SVR2_CHECK(d->resid == nullptr || (d->ldr % 8 == 0 && aligned16(d->resid)), SVR2_E_ALIGN,
+                       "svr2_gemm: resid alignment");
+            return launch<A_DENSE, SVR2_EPI_BIAS>(a, s);
+        case SVR2_EPI_GATE_RES:
+            SVR2_CHECK(d->resid && d->ldr % 8 == 0 && aligned16(d->resid) && d->N % 8 == 0, SVR2_E_ARG,
+                       "svr2_gemm: GATE_RES needs resid (16B aligned, ldr %% 8 == 0) and N %% 8 == 0");
+            return launch<A_DENSE, SVR2_EPI_GATE_RES>(a, s);
+        case SVR2_EPI_SWIGLU:
+            SVR2_CHECK(d->N % 16 == 0 && d->bias == nullptr, SVR2_E_SHAPE,
+                       "svr2_gemm: SWIGLU needs N %% 16 == 0 (interleaved gate/in rows) and no bias");
+            return launch<A_DENSE, SVR2_EPI_SWIGLU>(a, s);
+        case SVR2_EPI_PIXSHUF3D: {
+            a.ps_frames = d->ps_frames; a.ps_h = d->ps_h; a.ps_w = d->ps_w; a.ps_c = d->ps_c; a.ps_tz = d->ps_tz;
+            a.ps_drop = d->ps_drop_head;
+            SVR2_CHECK(d->ps_c > 0 && d->ps_c % 8 == 0 && (d->ps_tz == 1 || d->ps_tz == 2) &&
+                           d->N == (int64_t)d->ps_c * 4 * d->ps_tz &&
+                           d->M == (int64_t)d->ps_frames * d->ps_h * d->ps_w,
+                       SVR2_E_SHAPE, "svr2_gemm: PIXSHUF3D geometry mismatch");
+            SVR2_CHECK(!(d->ps_drop_head && d->ps_tz != 2), SVR2_E_SHAPE, "svr2_gemm: drop_head needs tz == 2");
+            return launch<A_DENSE, SVR2_EPI_PIXSHUF3D>(a, s);
+        }
+        default:
+            svr2_set_error("svr2_gemm: unknown epilogue %d", d->epilogue);
+            return SVR2_E_ARG;
+    }
+}
+
+extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
+    SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
+    SVR2_CHECK(d->Cin > 0 && d->Cin % BK == 0, SVR2_E_SHAPE, "svr2_conv3d: Cin %% 64 != 0 (Cin=%d); use svr2_im2col3d",
+               d->Cin);
+    SVR2_CHECK(d->Cout > 0 && d->Cout % 8 == 0, SVR2_E_SHAPE, "svr2_conv3d: Cout %% 8 != 0 (Cout=%d)", d->Cout);
+    SVR2_CHECK(d->kt >= 1 && d->kh >= 1 && d->kw >= 1 && d->st >= 1 && d->sh >= 1 && d->sw >= 1 && d->npad >= 0,
+               SVR2_E_SHAPE, "svr2_conv3d: bad kernel/stride");
+    SVR2_CHECK(d->T >= 1 && (d->T + d->npad - d->kt) >= 0 && d->To == (d->T + d->npad - d->kt) / d->st + 1,
+               SVR2_E_SHAPE, "svr2_conv3d: To=%d inconsistent with T=%d npad=%d kt=%d st=%d", d->To, d->T, d->npad,
+               d->kt, d->st);
+    // every input coordinate the kernel forms must be either in range or rejected by its bounds test:
+    SVR2_CHECK(d->Ho >= 1 && d->Wo >= 1 && (d->Ho - 1) * d->sh - d->pad_h0 < d->Hi &&
+                   (d->Wo - 1) * d->sw - d->pad_w0 < d->Wi,
+               SVR2_E_SHAPE, "svr2_conv3d: Ho/Wo inconsistent with input size");
+    SVR2_CHECK((d->To - 1) * d->st + d->kt - 1 < d->T + d->npad, SVR2_E_SHAPE, "svr2_conv3d: temporal overrun");
+    SVR2_CHECK(aligned16(d->x) && aligned16(d->w) && aligned16(d->y) && (!d->carry || aligned16(d->carry)) &&
+                   (!d->resid || aligned16(d->resid)),
+               SVR2_E_ALIGN, "svr2_conv3d: pointers must be 16-byte aligned");
+    const long long M = (long long)d->To * d->Ho * d->Wo;
+    SVR2_CHECK(M < (1ll << 31) - BM, SVR2_E_SHAPE, "svr2_conv3d: too many output pixels for one call");
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)d->x; a.W = (const bf16*)d->w; a.C = (bf16*)d->y;
+    a.bias = d->bias; a.resid = (const bf16*)d->resid; a.zero = (const bf16*)d->zero_page;
+    a.ldc = d->Cout; a.ldr = d->Cout;
+    a.M = (int)M; a.N = d->Cout; a.K = d->kt * d->kh * d->kw * d->Cin;
+    a.nbm = (a.M + BM - 1) / BM; a.nbn = (a.N + BN - 1) / BN;
+    a.cg.carry = (const bf16*)d->carry;
+    a.cg.T = d->T; a.cg.Hi = d->Hi; a.cg.Wi = d->Wi; a.cg.Cin = d->Cin;
+    a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
+    a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
+    a.cg.To = d->To; a.cg.Ho = d->Ho; a.cg.Wo = d->Wo;
+    return launch<A_CONV, SVR2_EPI_BIAS>(a, (hipStream_t)stream);
+}

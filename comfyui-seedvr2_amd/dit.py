@@ -1,0 +1,269 @@
+"""NaDiT (SeedVR2 3B / 7B-style) one-step forward on the HIP kernels.
+
+Mirrors the call structure of the reference's ``NaDiT.forward`` [ref: src/models/dit_3b/nadit.py:190-248]
+and ``NaMMSRTransformerBlock.forward`` [ref: src/models/dit_3b/nablocks/mmsr_block.py:84-128], but every
+stage is one launch of a fused kernel from libseedvr2_hip (see include/seedvr2_hip.h):
+
+    rmsnorm_mod -> gemm(qkv) -> qkv_prep (window gather + qk-norm + rope) -> window_attn
+    -> gemm(proj_out, fused window-reverse gather + bias + gate + residual)
+    -> rmsnorm_mod -> gemm(SwiGLU) -> gemm(proj_out, gate + residual)
+
+At inference the AdaSingle modulation is a set of per-layer constant vectors (the timestep embedding is
+fixed at t = T = 1000 for the one-step sampler [ref: src/core/generation_phases.py:595-597,
+src/models/dit_3b/modulation.py:65-118]); they are folded at load time into fp32 scale/shift/gate vectors,
+including the ``vid_out_ada`` cache-key collision [ref: nadit.py:234-244, common/cache.py:18-47].
+Weights are taken in the reference's state-dict layout.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from . import windows as W
+
+
+@dataclass
+class DiTConfig:
+    vid_in_channels: int = 33
+    vid_out_channels: int = 16
+    vid_dim: int = 2560
+    txt_in_dim: int = 5120
+    heads: int = 20
+    head_dim: int = 128
+    expand_ratio: int = 4
+    num_layers: int = 32
+    mm_layers: int = 10
+    norm_eps: float = 1e-5
+    window: Tuple[int, int, int] = (4, 3, 3)
+    mlp_multiple_of: int = 256
+    rope_mode: int = 1  # 1 = 3B mm-rope ('lang'), 0 = none
+
+    @property
+    def mlp_hidden(self) -> int:
+        hid = int(2 * self.vid_dim * self.expand_ratio / 3)  # [ref: dit_3b/mlp.py:54-55]
+        m = self.mlp_multiple_of
+        return m * ((hid + m - 1) // m)
+
+    def shared(self, i: int) -> bool:
+        return not (i < self.mm_layers)  # [ref: dit_3b/nadit.py:149-151]
+
+    def method(self, i: int) -> str:
+        return W.REGULAR if i % 2 == 0 else W.SHIFTED  # [ref: configs_3b/main.yaml:34]
+
+
+CFG_3B = DiTConfig()
+
+
+def _timestep_embedding(t: float, dim: int = 256) -> torch.Tensor:
+    """[sin(t f), cos(t f)], f_i = exp(-ln(1e4) i / half)  (diffusers get_timestep_embedding as called at
+    [ref: src/models/dit_3b/embedding.py:50-55]: flip_sin_to_cos=False, downscale_freq_shift=0)."""
+    half = dim // 2
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = torch.tensor([float(t)], dtype=torch.float32)[:, None] * f[None]
+    return torch.cat((a.sin(), a.cos()), dim=-1)
+
+
+class NaDiTHip:
+    def __init__(self, cfg: DiTConfig, params: Dict[str, torch.Tensor], device, timestep: float = 1000.0):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._plans = {}
+        d = cfg.vid_dim
+        dev = self.device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        # ---- constant time embedding -> modulation vectors (fp32)  [ref: dit_3b/embedding.py:39-62]
+        e = _timestep_embedding(timestep).to(dev)
+        lin = lambda x, k: torch.nn.functional.linear(x, f32(params[k + ".weight"]), f32(params[k + ".bias"]))
+        e = torch.nn.functional.silu(lin(e, "emb_in.proj_in"))
+        e = torch.nn.functional.silu(lin(e, "emb_in.proj_hid"))
+        emb = lin(e, "emb_in.proj_out")[0].reshape(d, 2, 3)  # [d, layer, (shift, scale, gate)]
+        self.emb = emb
+
+        self.w_vid_in = hip.pad_weight(params["vid_in.proj.weight"].to(dev))
+        self.b_vid_in = f32(params["vid_in.proj.bias"])
+        self.kpad_in = self.w_vid_in.shape[1]
+        self.w_txt_in = hip.pad_weight(params["txt_in.weight"].to(dev))
+        self.b_txt_in = f32(params["txt_in.bias"])
+        self.w_vid_out = hip.pad_weight(params["vid_out.proj.weight"].to(dev))
+        self.b_vid_out = f32(params["vid_out.proj.bias"])
+        # vid_out_norm (affine) + vid_out_ada reuse of the attn-layer slice  [ref: nadit.py:234-244]
+        self.out_scale = (f32(params["vid_out_norm.weight"]) * (emb[:, 0, 1] + f32(params["vid_out_ada.out_scale"]))).contiguous()
+        self.out_shift = (emb[:, 0, 0] + f32(params["vid_out_ada.out_shift"])).contiguous()
+
+        ones = torch.ones(d, dtype=torch.float32, device=dev)
+        self.layers = []
+        for i in range(cfg.num_layers):
+            last = i == cfg.num_layers - 1
+            bv, bt = ("all", "all") if cfg.shared(i) else ("vid", "txt")
+            pre = f"blocks.{i}."
+            L = {}
+            for tag, b in (("v", bv), ("t", bt)):
+                if tag == "t" and b == bv and "v" in L:
+                    L["t"] = L["v"] if not last else self._txt_last_layer(L["v"], ones)
+                    continue
+                g = lambda name: params[pre + name]
+                ent = {
+                    "w_qkv": hip.pad_weight(g(f"attn.proj_qkv.{b}.weight").to(dev)),
+                    "w_out": hip.pad_weight(g(f"attn.proj_out.{b}.weight").to(dev)),
+                    "b_out": f32(g(f"attn.proj_out.{b}.bias")),
+                    "qn": f32(g(f"attn.norm_q.{b}.weight")), "kn": f32(g(f"attn.norm_k.{b}.weight")),
+                }
+                vid_only_skip = last and tag == "t"
+                if not vid_only_skip:
+                    ent.update({
+                        "w_gi": hip.pad_weight(hip.interleave_swiglu(g(f"mlp.{b}.proj_in_gate.weight").to(dev),
+                                                                     g(f"mlp.{b}.proj_in.weight").to(dev))),
+                        "w_mo": hip.pad_weight(g(f"mlp.{b}.proj_out.weight").to(dev)),
+                    })
+                    for li, lname in enumerate(("attn", "mlp")):
+                        ent[f"{lname}_scale"] = (emb[:, li, 1] + f32(g(f"ada.{b}.{lname}_scale"))).contiguous()
+                        ent[f"{lname}_shift"] = (emb[:, li, 0] + f32(g(f"ada.{b}.{lname}_shift"))).contiguous()
+                        ent[f"{lname}_gate"] = (emb[:, li, 2] + f32(g(f"ada.{b}.{lname}_gate"))).contiguous()
+                else:  # last layer: ada/mlp are vid_only -> text is only normalised  [ref: mmsr_block.py:73-82]
+                    ent.update({"attn_scale": ones, "attn_shift": None, "attn_gate": ones})
+                L[tag] = ent
+            self.layers.append(L)
+
+        # rope tables (3B): angle = pos * theta^(-2i/42), i < 21  [ref: dit_3b/rope.py:74-85]
+        nfreq = (cfg.head_dim // 3) // 2
+        fr = 1.0 / (10000.0 ** (torch.arange(0, cfg.head_dim // 3, 2)[:nfreq].float() / (cfg.head_dim // 3)))
+        ang = torch.arange(1024, dtype=torch.float32)[:, None] * fr[None]
+        self.rope_cos = ang.cos().contiguous().to(dev)
+        self.rope_sin = ang.sin().contiguous().to(dev)
+
+    @staticmethod
+    def _txt_last_layer(v_ent, ones):
+        ent = dict(v_ent)
+        ent.update({"attn_scale": ones, "attn_shift": None, "attn_gate": ones})
+        for k in ("w_gi", "w_mo", "mlp_scale", "mlp_shift", "mlp_gate"):
+            ent.pop(k, None)
+        return ent
+
+    # ------------------------------------------------------------------ window tables on the device
+    def _plan(self, grid, method: str, txt_len: int):
+        key = (grid, method, txt_len)
+        if key not in self._plans:
+            p = W.plan(grid, method, txt_len, self.cfg.window)
+            if p.max_pos > self.rope_cos.shape[0]:
+                raise hip.HipError(f"rope table too small for position {p.max_pos}")
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            self._plans[key] = {
+                "S": p.total, "nwin": p.nwin, "src_row": up(p.src_row), "pos": up(p.pos), "cu": up(p.cu_seqlens),
+                "tile_seq": up(p.tile_seq), "tile_q0": up(p.tile_q0), "inv_rows": up(p.inv_rows),
+                "txt_row0": up(p.txt_row0),
+            }
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ forward
+    def block(self, i: int, x: torch.Tensor, y: torch.Tensor, grid, taps=None):
+        cfg = self.cfg
+        last = i == cfg.num_layers - 1
+        Lv, Lt_ = self.layers[i]["v"], self.layers[i]["t"]
+        H, D, d = cfg.heads, cfg.head_dim, cfg.vid_dim
+        ntxt = y.shape[0]
+        pl = self._plan(grid, cfg.method(i), ntxt)
+        # attention half
+        xa = hip.rmsnorm_mod(x, Lv["attn_scale"], Lv["attn_shift"], cfg.norm_eps)
+        ya = hip.rmsnorm_mod(y, Lt_["attn_scale"], Lt_["attn_shift"], cfg.norm_eps)
+        qkv_v = hip.gemm(xa, Lv["w_qkv"], 3 * H * D)
+        qkv_t = hip.gemm(ya, Lt_["w_qkv"], 3 * H * D)
+        qkvw = hip.qkv_prep(qkv_v, qkv_t, pl["src_row"], pl["pos"], Lv["qn"], Lv["kn"], Lt_["qn"], Lt_["kn"],
+                            self.rope_cos, self.rope_sin, H, cfg.rope_mode, cfg.norm_eps)
+        del qkv_v, qkv_t, xa, ya
+        o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D))
+        del qkvw
+        o2 = o.view(pl["S"], H * D)
+        ot = hip.txt_mean(o2, pl["txt_row0"], ntxt)
+        x1 = hip.gemm(o2, Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"], resid=x,
+                      a_rows=pl["inv_rows"], m=x.shape[0])
+        y1 = hip.gemm(ot, Lt_["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lt_["b_out"], gate=Lt_["attn_gate"], resid=y)
+        if taps is not None:
+            taps["x1"] = x1; taps["y1"] = y1
+        del o, o2
+        # mlp half
+        xm = hip.rmsnorm_mod(x1, Lv["mlp_scale"], Lv["mlp_shift"], cfg.norm_eps)
+        hmid = hip.gemm(xm, Lv["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
+        x2 = hip.gemm(hmid, Lv["w_mo"], d, epilogue=hip.EPI_GATE_RES, gate=Lv["mlp_gate"], resid=x1)
+        del xm, hmid
+        if not last:
+            ym = hip.rmsnorm_mod(y1, Lt_["mlp_scale"], Lt_["mlp_shift"], cfg.norm_eps)
+            ht = hip.gemm(ym, Lt_["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
+            y2 = hip.gemm(ht, Lt_["w_mo"], d, epilogue=hip.EPI_GATE_RES, gate=Lt_["mlp_gate"], resid=y1)
+        else:
+            y2 = y1  # unused downstream
+        return x2, y2
+
+    @torch.no_grad()
+    def one_step(self, noise: torch.Tensor, latent: torch.Tensor, txt: torch.Tensor, taps=None) -> torch.Tensor:
+        """x0 = noise - NaDiT(cat[noise, latent, 1])  [ref: src/core/infer.py:54-78,294-374;
+        common/diffusion/schedules/base.py:108-110].  noise, latent: bf16 [T,H,W,16]; txt bf16 [Lt, txt_in_dim]."""
+        cfg = self.cfg
+        T, Hh, Ww, Cc = noise.shape
+        if Hh % 2 or Ww % 2:
+            raise hip.HipError("latent H and W must be even (patch size 2)")
+        if 2 * Cc + 1 != cfg.vid_in_channels:
+            raise hip.HipError("latent channel count does not match vid_in_channels")
+        grid = (T, Hh // 2, Ww // 2)
+        rows = hip.patch_in(noise, latent, self.kpad_in)
+        x = hip.gemm(rows, self.w_vid_in, cfg.vid_dim, bias=self.b_vid_in)
+        del rows
+        txt = txt.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        y = hip.gemm(txt, self.w_txt_in, cfg.vid_dim, bias=self.b_txt_in)
+        if taps is not None:
+            taps["x0"] = x; taps["y0"] = y
+        for i in range(cfg.num_layers):
+            x, y = self.block(i, x, y, grid, taps if (taps is not None and i == 0) else None)
+            if taps is not None:
+                taps[f"x{i + 1}"] = x
+        xo = hip.rmsnorm_mod(x, self.out_scale, self.out_shift, cfg.norm_eps)
+        pred = hip.gemm(xo, self.w_vid_out, cfg.vid_out_channels * 4, bias=self.b_vid_out)
+        return hip.patch_out_x0(pred, noise)
+
+
+def synthetic_state_dict(cfg: DiTConfig, device, seed: int = 0, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the right architecture generated on `device` (bench only: there is no
+    checkpoint offline).  Same key layout as the reference state dict; fan-in scaled so activations stay O(1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    d, hd, H = cfg.vid_dim, cfg.head_dim, cfg.heads
+    out: Dict[str, torch.Tensor] = {}
+
+    def mat(n, k):
+        return (torch.randn(n, k, generator=g, device=device, dtype=torch.float32) / math.sqrt(k)).to(dtype)
+
+    def vec(n, mean=0.0, std=0.02):
+        return (mean + std * torch.randn(n, generator=g, device=device, dtype=torch.float32)).to(dtype)
+
+    out["vid_in.proj.weight"] = mat(d, cfg.vid_in_channels * 4); out["vid_in.proj.bias"] = vec(d)
+    out["txt_in.weight"] = mat(d, cfg.txt_in_dim); out["txt_in.bias"] = vec(d)
+    out["emb_in.proj_in.weight"] = mat(d, 256); out["emb_in.proj_in.bias"] = vec(d)
+    out["emb_in.proj_hid.weight"] = mat(d, d); out["emb_in.proj_hid.bias"] = vec(d)
+    out["emb_in.proj_out.weight"] = mat(6 * d, d); out["emb_in.proj_out.bias"] = vec(6 * d)
+    out["vid_out_norm.weight"] = vec(d, 1.0, 0.1)
+    out["vid_out_ada.out_shift"] = vec(d, 0.0, 1 / math.sqrt(d)); out["vid_out_ada.out_scale"] = vec(d, 1.0, 1 / math.sqrt(d))
+    out["vid_out.proj.weight"] = mat(cfg.vid_out_channels * 4, d); out["vid_out.proj.bias"] = vec(cfg.vid_out_channels * 4)
+    for i in range(cfg.num_layers):
+        last = i == cfg.num_layers - 1
+        p = f"blocks.{i}."
+        for b in (("all",) if cfg.shared(i) else ("vid", "txt")):
+            out[p + f"attn.proj_qkv.{b}.weight"] = mat(3 * H * hd, d)
+            out[p + f"attn.proj_out.{b}.weight"] = mat(d, H * hd)
+            out[p + f"attn.proj_out.{b}.bias"] = vec(d)
+            out[p + f"attn.norm_q.{b}.weight"] = vec(hd, 1.0, 0.1)
+            out[p + f"attn.norm_k.{b}.weight"] = vec(hd, 1.0, 0.1)
+            if last and b == "txt":
+                continue
+            out[p + f"mlp.{b}.proj_in_gate.weight"] = mat(cfg.mlp_hidden, d)
+            out[p + f"mlp.{b}.proj_in.weight"] = mat(cfg.mlp_hidden, d)
+            out[p + f"mlp.{b}.proj_out.weight"] = mat(d, cfg.mlp_hidden)
+            for l in ("attn", "mlp"):
+                out[p + f"ada.{b}.{l}_shift"] = vec(d, 0.0, 1 / math.sqrt(d))
+                out[p + f"ada.{b}.{l}_scale"] = vec(d, 1.0, 1 / math.sqrt(d))
+                out[p + f"ada.{b}.{l}_gate"] = vec(d, 0.5, 1 / math.sqrt(d))
+    return out

@@ -1,0 +1,368 @@
+"""ctypes binding of libseedvr2_hip.so (the C ABI declared in include/seedvr2_hip.h).
+
+PyTorch-ROCm is used only as the owner of device memory and streams: every wrapper takes
+torch tensors, checks shapes/dtypes on the host, and passes raw device pointers plus the
+current HIP stream to the library.  There is NO fallback: if the shared library is missing
+or the device is not gfx950 the import / first call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseedvr2_hip.so")
+
+EPI_BIAS, EPI_GATE_RES, EPI_SWIGLU, EPI_PIXSHUF3D = 0, 1, 2, 3
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_rows", C.c_void_p),
+        ("W", C.c_void_p), ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("epilogue", C.c_int32),
+        ("bias", C.c_void_p), ("gate", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64),
+        ("ps_frames", C.c_int32), ("ps_h", C.c_int32), ("ps_w", C.c_int32), ("ps_c", C.c_int32),
+        ("ps_tz", C.c_int32), ("ps_drop_head", C.c_int32),
+        ("zero_page", C.c_void_p),
+    ]
+
+
+class Conv3dDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("carry", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("resid", C.c_void_p), ("y", C.c_void_p),
+        ("T", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("st", C.c_int32), ("sh", C.c_int32),
+        ("sw", C.c_int32),
+        ("npad", C.c_int32), ("pad_h0", C.c_int32), ("pad_w0", C.c_int32),
+        ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("zero_page", C.c_void_p),
+    ]
+
+
+class QkvPrepDesc(C.Structure):
+    _fields_ = [
+        ("qkv_vid", C.c_void_p), ("qkv_txt", C.c_void_p), ("src_row", C.c_void_p), ("pos", C.c_void_p),
+        ("qn_vid", C.c_void_p), ("kn_vid", C.c_void_p), ("qn_txt", C.c_void_p), ("kn_txt", C.c_void_p),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("S", C.c_int64),
+        ("H", C.c_int32), ("D", C.c_int32), ("nfreq", C.c_int32), ("max_pos", C.c_int32),
+        ("rope_mode", C.c_int32), ("eps", C.c_float),
+    ]
+
+
+_lib = None
+_zero_pages = {}
+
+# every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
+    "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_txt_mean", "svr2_patch_in",
+    "svr2_patch_out_x0",
+]
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises if it was not built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "The SeedVR2 MI355X path has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.svr2_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if name != "svr2_last_error" and hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed (code {rc}): {lib().svr2_last_error().decode()}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def zero_page(device) -> torch.Tensor:
+    dev = torch.device(device)
+    key = (dev.type, dev.index)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    return _zero_pages[key]
+
+
+def device_check(index: int = 0) -> int:
+    rc = lib().svr2_device_check(C.c_int(index))
+    if rc <= 0:
+        _check(rc, "svr2_device_check")
+    return rc
+
+
+def _bf16c(t: torch.Tensor, name: str):
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise HipError(f"{name}: expected a bf16 device tensor, got {t.dtype} on {t.device}")
+
+
+def _f32c(t: Optional[torch.Tensor], name: str, n: Optional[int] = None):
+    if t is None:
+        return
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise HipError(f"{name}: expected a contiguous fp32 device tensor")
+    if n is not None and t.numel() < n:
+        raise HipError(f"{name}: expected at least {n} elements, got {t.numel()}")
+
+
+def pad_weight(w: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
+    """[N, K] -> bf16 [round_up(N,128), kpad or round_up(K,64)] zero padded (the layout svr2_gemm wants)."""
+    n, k = w.shape
+    kp = kpad if kpad is not None else (k + 63) // 64 * 64
+    out = torch.zeros((n + 127) // 128 * 128, kp, dtype=torch.bfloat16, device=w.device)
+    out[:n, :k] = w.to(torch.bfloat16)
+    return out
+
+
+def interleave_swiglu(w_gate: torch.Tensor, w_in: torch.Tensor) -> torch.Tensor:
+    """Rows [8 gate | 8 in] per 16 (SVR2_EPI_SWIGLU).  w_*: [hidden, K]; hidden % 8 == 0."""
+    h, k = w_gate.shape
+    assert h % 8 == 0 and w_in.shape == w_gate.shape
+    return torch.stack((w_gate.reshape(h // 8, 8, k), w_in.reshape(h // 8, 8, k)), dim=1).reshape(2 * h, k)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, n: int, out: Optional[torch.Tensor] = None, *, epilogue: int = EPI_BIAS,
+         bias: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+         resid: Optional[torch.Tensor] = None, a_rows: Optional[torch.Tensor] = None, m: Optional[int] = None,
+         pixshuf: Optional[tuple] = None) -> torch.Tensor:
+    """out[M, N'] = epilogue(a[M, K] @ w[:n, K]^T).  `w` is a pad_weight()-style matrix."""
+    _bf16c(a, "gemm.a"); _bf16c(w, "gemm.w")
+    if a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or not w.is_contiguous():
+        raise HipError("gemm: a must be [M,K] with unit inner stride, w contiguous [n_pad,K]")
+    K = w.shape[1]
+    M = int(m if m is not None else (a_rows.numel() if a_rows is not None else a.shape[0]))
+    if a.shape[1] != K or K % 64 or w.shape[0] % 128 or w.shape[0] < n:
+        raise HipError(f"gemm: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} n={n}")
+    if a_rows is None and a.shape[0] < M:
+        raise HipError("gemm: a has fewer rows than M")
+    if a_rows is not None and (a_rows.dtype != torch.int32 or not a_rows.is_cuda or a_rows.numel() < M):
+        raise HipError("gemm: a_rows must be an int32 device tensor with >= M entries")
+    n_out = n // 2 if epilogue == EPI_SWIGLU else n
+    d = GemmDesc()
+    if epilogue == EPI_PIXSHUF3D:
+        frames, h_, w_, c_, tz, drop = pixshuf
+        fo = frames * tz - (1 if drop else 0)
+        if out is None:
+            out = torch.empty(fo, 2 * h_, 2 * w_, c_, dtype=torch.bfloat16, device=a.device)
+        if out.numel() != fo * 4 * h_ * w_ * c_ or not out.is_contiguous():
+            raise HipError("gemm: pixel-shuffle output has the wrong size")
+        d.ps_frames, d.ps_h, d.ps_w, d.ps_c, d.ps_tz, d.ps_drop_head = frames, h_, w_, c_, tz, int(bool(drop))
+        ldc = c_
+    else:
+        if out is None:
+            out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
+        _bf16c(out, "gemm.out")
+        if out.dim() != 2 or out.shape[0] < M or out.shape[1] < n_out or out.stride(1) != 1:
+            raise HipError("gemm: out too small")
+        ldc = out.stride(0)
+    _f32c(bias, "gemm.bias", n); _f32c(gate, "gemm.gate", n)
+    if resid is not None:
+        _bf16c(resid, "gemm.resid")
+        if resid.dim() != 2 or resid.shape[0] < M or resid.shape[1] < n or resid.stride(1) != 1:
+            raise HipError("gemm: resid too small")
+    d.M, d.N, d.K = M, n, K
+    d.A, d.lda, d.a_rows = a.data_ptr(), a.stride(0), (a_rows.data_ptr() if a_rows is not None else None)
+    d.W, d.C, d.ldc, d.epilogue = w.data_ptr(), out.data_ptr(), ldc, epilogue
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.gate = gate.data_ptr() if gate is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.ldr = resid.stride(0) if resid is not None else 0
+    d.zero_page = zero_page(a.device).data_ptr()
+    _check(lib().svr2_gemm(C.byref(d), _stream()), "svr2_gemm")
+    return out
+
+
+def conv_out_size(t, hi, wi, k, s, npad, pad_hw):
+    """Output extent of the causal conv: pad_hw = (h0, h1, w0, w1) zero padding."""
+    kt, kh, kw = k
+    st, sh, sw = s
+    to = (t + npad - kt) // st + 1
+    ho = (hi + pad_hw[0] + pad_hw[1] - kh) // sh + 1
+    wo = (wi + pad_hw[2] + pad_hw[3] - kw) // sw + 1
+    return to, ho, wo
+
+
+def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y):
+    T, Hi, Wi, Cin = x.shape
+    To, Ho, Wo = conv_out_size(T, Hi, Wi, k, s, npad, pad_hw)
+    d = Conv3dDesc()
+    d.x, d.carry, d.w = x.data_ptr(), (carry.data_ptr() if carry is not None else None), w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.y = y.data_ptr() if y is not None else None
+    d.T, d.Hi, d.Wi, d.Cin, d.Cout = T, Hi, Wi, Cin, cout
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = s
+    d.npad, d.pad_h0, d.pad_w0 = npad, pad_hw[0], pad_hw[2]
+    d.To, d.Ho, d.Wo = To, Ho, Wo
+    d.zero_page = zero_page(x.device).data_ptr()
+    return d, (To, Ho, Wo)
+
+
+def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad: int, pad_hw=(1, 1, 1, 1),
+           carry: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+           resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w [cout_pad, kt*kh*kw*Cin] bf16 (tap-major, Cin fastest)."""
+    _bf16c(x, "conv3d.x"); _bf16c(w, "conv3d.w")
+    if x.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
+        raise HipError("conv3d: x must be contiguous [T,H,W,C]")
+    T, Hi, Wi, Cin = x.shape
+    if w.shape[1] != k[0] * k[1] * k[2] * Cin or w.shape[0] % 128 or w.shape[0] < cout:
+        raise HipError(f"conv3d: weight shape {tuple(w.shape)} does not match k={k} Cin={Cin} cout={cout}")
+    if carry is not None:
+        _bf16c(carry, "conv3d.carry")
+        if tuple(carry.shape) != (npad, Hi, Wi, Cin) or not carry.is_contiguous():
+            raise HipError(f"conv3d: carry must be [{npad},{Hi},{Wi},{Cin}], got {tuple(carry.shape)}")
+    To, Ho, Wo = conv_out_size(T, Hi, Wi, k, s, npad, pad_hw)
+    if To < 1 or Ho < 1 or Wo < 1:
+        raise HipError("conv3d: empty output")
+    if out is None:
+        out = torch.empty(To, Ho, Wo, cout, dtype=torch.bfloat16, device=x.device)
+    if tuple(out.shape) != (To, Ho, Wo, cout) or not out.is_contiguous():
+        raise HipError("conv3d: out has the wrong shape")
+    _f32c(bias, "conv3d.bias", cout)
+    if resid is not None and (tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
+        raise HipError("conv3d: resid must match the output shape")
+    d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out)
+    _check(lib().svr2_conv3d(C.byref(d), _stream()), "svr2_conv3d")
+    return out
+
+
+def im2col3d(x: torch.Tensor, k, s, *, npad: int, pad_hw, carry: Optional[torch.Tensor], kpad: int) -> torch.Tensor:
+    _bf16c(x, "im2col3d.x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise HipError("im2col3d: x must be contiguous [T,H,W,C]")
+    if carry is not None and (tuple(carry.shape) != (npad,) + tuple(x.shape[1:]) or not carry.is_contiguous()):
+        raise HipError("im2col3d: bad carry shape")
+    d, (To, Ho, Wo) = _conv_desc(x, x, 8, k, s, npad, pad_hw, carry, None, None, None)
+    col = torch.empty(To * Ho * Wo, kpad, dtype=torch.bfloat16, device=x.device)
+    _check(lib().svr2_im2col3d(C.byref(d), _p(col), C.c_int64(kpad), _stream()), "svr2_im2col3d")
+    return col
+
+
+def rmsnorm_mod(x: torch.Tensor, scale: torch.Tensor, shift: Optional[torch.Tensor], eps: float,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "rmsnorm_mod.x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise HipError("rmsnorm_mod: x must be contiguous [rows, dim]")
+    rows, dim = x.shape
+    _f32c(scale, "rmsnorm_mod.scale", dim); _f32c(shift, "rmsnorm_mod.shift", dim)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().svr2_rmsnorm_mod(_p(x), _p(out), _p(scale), _p(shift), C.c_int64(rows), C.c_int32(dim),
+                                  C.c_float(eps), _stream()), "svr2_rmsnorm_mod")
+    return out
+
+
+def qkv_prep(qkv_vid, qkv_txt, src_row, pos, qn_vid, kn_vid, qn_txt, kn_txt, rope_cos, rope_sin, heads: int,
+             rope_mode: int, eps: float, out=None):
+    _bf16c(qkv_vid, "qkv_prep.qkv_vid"); _bf16c(qkv_txt, "qkv_prep.qkv_txt")
+    D = 128
+    if qkv_vid.shape[1] != 3 * heads * D or qkv_txt.shape[1] != 3 * heads * D:
+        raise HipError("qkv_prep: qkv must be [rows, 3*H*128]")
+    if not (qkv_vid.is_contiguous() and qkv_txt.is_contiguous()):
+        raise HipError("qkv_prep: qkv must be contiguous")
+    S = src_row.numel()
+    if src_row.dtype != torch.int32 or (pos is not None and (pos.dtype != torch.int32 or pos.numel() != 3 * S)):
+        raise HipError("qkv_prep: src_row/pos must be int32, pos [S,3]")
+    for t_, nm in ((qn_vid, "qn_vid"), (kn_vid, "kn_vid"), (qn_txt, "qn_txt"), (kn_txt, "kn_txt")):
+        _f32c(t_, "qkv_prep." + nm, D)
+    if out is None:
+        out = torch.empty(3, S, heads, D, dtype=torch.bfloat16, device=qkv_vid.device)
+    d = QkvPrepDesc()
+    d.qkv_vid, d.qkv_txt, d.src_row, d.pos = qkv_vid.data_ptr(), qkv_txt.data_ptr(), src_row.data_ptr(), \
+        (pos.data_ptr() if pos is not None else None)
+    d.qn_vid, d.kn_vid, d.qn_txt, d.kn_txt = qn_vid.data_ptr(), kn_vid.data_ptr(), qn_txt.data_ptr(), kn_txt.data_ptr()
+    nfreq, max_pos = 0, 0
+    if rope_mode != 0:
+        _f32c(rope_cos, "qkv_prep.rope_cos"); _f32c(rope_sin, "qkv_prep.rope_sin")
+        d.rope_cos, d.rope_sin = rope_cos.data_ptr(), rope_sin.data_ptr()
+        if rope_mode == 1:
+            max_pos, nfreq = rope_cos.shape
+        else:
+            nfreq = rope_cos.shape[1] // 3
+            if rope_cos.shape[0] != S:
+                raise HipError("qkv_prep: per-position rope tables must have S rows")
+    d.q, d.k, d.v = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+    d.S, d.H, d.D, d.nfreq, d.max_pos, d.rope_mode, d.eps = S, heads, D, nfreq, max_pos, rope_mode, eps
+    _check(lib().svr2_qkv_prep(C.byref(d), _stream()), "svr2_qkv_prep")
+    return out
+
+
+def window_attn(q, k, v, cu_seqlens, tile_seq, tile_q0, scale: float, out=None):
+    for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _bf16c(t_, "window_attn." + nm)
+        if t_.dim() != 3 or t_.shape[2] != 128 or not t_.is_contiguous() or t_.shape != q.shape:
+            raise HipError("window_attn: q,k,v must be contiguous [S,H,128] of equal shape")
+    for t_ in (cu_seqlens, tile_seq, tile_q0):
+        if t_.dtype != torch.int32 or not t_.is_cuda:
+            raise HipError("window_attn: index tensors must be int32 on the device")
+    if tile_seq.numel() != tile_q0.numel():
+        raise HipError("window_attn: tile list mismatch")
+    if out is None:
+        out = torch.empty_like(q)
+    _check(lib().svr2_window_attn(_p(q), _p(k), _p(v), _p(out), _p(cu_seqlens), _p(tile_seq), _p(tile_q0),
+                                  C.c_int32(tile_seq.numel()), C.c_int32(q.shape[1]), C.c_int32(128),
+                                  C.c_float(scale), _stream()), "svr2_window_attn")
+    return out
+
+
+def txt_mean(attn: torch.Tensor, txt_row0: torch.Tensor, lt: int, out=None):
+    _bf16c(attn, "txt_mean.attn")
+    if attn.dim() != 2 or not attn.is_contiguous() or txt_row0.dtype != torch.int32:
+        raise HipError("txt_mean: attn must be contiguous [S, dim], txt_row0 int32")
+    dim = attn.shape[1]
+    if out is None:
+        out = torch.empty(lt, dim, dtype=torch.bfloat16, device=attn.device)
+    _check(lib().svr2_txt_mean(_p(attn), _p(txt_row0), C.c_int32(txt_row0.numel()), C.c_int32(lt), C.c_int32(dim),
+                               _p(out), _stream()), "svr2_txt_mean")
+    return out
+
+
+def patch_in(noise: torch.Tensor, latent: torch.Tensor, kpad: int) -> torch.Tensor:
+    _bf16c(noise, "patch_in.noise"); _bf16c(latent, "patch_in.latent")
+    if noise.shape != latent.shape or noise.dim() != 4 or not (noise.is_contiguous() and latent.is_contiguous()):
+        raise HipError("patch_in: noise/latent must be contiguous [T,H,W,C] of equal shape")
+    T, H, W, Cc = noise.shape
+    rows = torch.empty(T * (H // 2) * (W // 2), kpad, dtype=torch.bfloat16, device=noise.device)
+    _check(lib().svr2_patch_in(_p(noise), _p(latent), _p(rows), C.c_int32(T), C.c_int32(H), C.c_int32(W),
+                               C.c_int32(Cc), C.c_int32(kpad), _stream()), "svr2_patch_in")
+    return rows
+
+
+def patch_out_x0(pred: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    _bf16c(pred, "patch_out_x0.pred"); _bf16c(noise, "patch_out_x0.noise")
+    T, H, W, Cc = noise.shape
+    if pred.dim() != 2 or pred.shape[0] < T * (H // 2) * (W // 2) or pred.shape[1] < 4 * Cc or pred.stride(1) != 1 \
+            or not noise.is_contiguous():
+        raise HipError("patch_out_x0: pred must be [L, >=4C]")
+    x0 = torch.empty_like(noise)
+    _check(lib().svr2_patch_out_x0(_p(pred), C.c_int64(pred.stride(0)), _p(noise), _p(x0), C.c_int32(T),
+                                   C.c_int32(H), C.c_int32(W), C.c_int32(Cc), _stream()), "svr2_patch_out_x0")
+    return x0

@@ -1,0 +1,186 @@
+/* libseedvr2_hip.so - C ABI of the MI355X (gfx950) SeedVR2 hot path.
+ *
+ * The reference (disk02/ComfyUI-SeedVR2 v2.5.18) is 100 % Python and has no FFI: every
+ * entry point below replaces an ATen call (or a Python loop over ATen calls) that the
+ * reference issues on its hot path; the reference call site each one replaces is cited
+ * as  [ref: file:line]  relative to /root/reference/src.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
+ *     the library never allocates, frees or synchronises; scratch is passed in explicitly.
+ *   - every call is asynchronous on `stream` (a hipStream_t, pass torch's current stream).
+ *   - returns 0 on success, a negative SVR2_E_* code otherwise; svr2_last_error() returns
+ *     a thread-local message for the last failing call of the calling thread.
+ *   - activations are bf16, row-major, channels-last; accumulation is fp32;
+ *     per-channel vectors (bias, modulation, norm weights) are fp32.
+ *   - no global mutable state; safe to call from several host threads / streams.
+ */
+#ifndef SEEDVR2_HIP_H
+#define SEEDVR2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVR2_ABI_VERSION 1
+
+enum {
+    SVR2_OK = 0,
+    SVR2_E_SHAPE = -1,  /* inconsistent sizes / unsupported geometry */
+    SVR2_E_ALIGN = -2,  /* pointer or leading dimension not 16-byte aligned */
+    SVR2_E_ARG = -3,    /* null pointer / bad enum */
+    SVR2_E_ARCH = -4,   /* device is not gfx950 */
+    SVR2_E_LAUNCH = -5  /* HIP launch error */
+};
+
+int svr2_abi_version(void);
+const char* svr2_last_error(void);
+/* Checks that device `dev` is gfx950 and returns its CU count (>0) or an error code. */
+int svr2_device_check(int dev);
+
+/* ------------------------------------------------------------------ GEMM (+ fused epilogues)
+ * C[M,N] = epilogue( A[M,K] * W[N,K]^T ),  bf16 in, fp32 accumulate, bf16 out.
+ * Replaces nn.Linear / F.linear on the DiT path
+ *   [ref: models/dit_3b/nablocks/attention/mmattn.py:56-59,173,269; mlp.py:56-61;
+ *         patch/patch_v1.py:96,114; nadit.py:114-118]
+ * and the 1x1x1 convolutions of the VAE [ref: models/video_vae_v3/modules/attn_video_vae.py:96-98].
+ *   W must be allocated with n_pad = round_up(N,128) rows (rows >= N zero), K % 64 == 0.
+ *   a_rows (optional): A row used for output row m is a_rows[m] (fused window_reverse gather,
+ *   [ref: models/dit_3b/na.py:637-638]).
+ * Epilogues:
+ *   SVR2_EPI_BIAS       C = acc + bias                     (bias may be NULL)
+ *   SVR2_EPI_GATE_RES   C = resid + gate * (acc + bias)    AdaSingle 'out' gate + residual add fused
+ *                        [ref: modulation.py:112-116, nablocks/mmsr_block.py:112-113,125-126]
+ *   SVR2_EPI_SWIGLU     W rows interleaved [8 gate | 8 in] per 16; C[M,N/2] = silu(g) * i
+ *                        [ref: models/dit_3b/mlp.py:60-61]
+ *   SVR2_EPI_PIXSHUF3D  Upsample3D: 1x1x1 conv C->C*r then 'b (x y z c) f h w -> b c (f z)(h x)(w y)',
+ *                        optional remove_head [ref: attn_video_vae.py:135-143,152-153;
+ *                        causal_inflation_lib.py:412-419]; A rows are (f,h,w) raster, C is [F',2H,2W,C].
+ */
+enum { SVR2_EPI_BIAS = 0, SVR2_EPI_GATE_RES = 1, SVR2_EPI_SWIGLU = 2, SVR2_EPI_PIXSHUF3D = 3 };
+
+typedef struct svr2_gemm_desc {
+    int64_t M, N, K;
+    const void* A;         /* bf16 [*, lda] */
+    int64_t lda;
+    const int32_t* a_rows; /* optional [M] */
+    const void* W;         /* bf16 [n_pad, K] */
+    void* C;               /* bf16 */
+    int64_t ldc;
+    int32_t epilogue;
+    const float* bias;     /* [N] or NULL */
+    const float* gate;     /* [N]      (GATE_RES) */
+    const void* resid;     /* bf16 [M, ldr] (GATE_RES) */
+    int64_t ldr;
+    /* PIXSHUF3D geometry: A rows = f*(ph*pw) + h*pw + w */
+    int32_t ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop_head;
+    const void* zero_page; /* >= 256 bytes of zeros (device) */
+} svr2_gemm_desc;
+
+int svr2_gemm(const svr2_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ causal 3-D convolution
+ * Implicit-GEMM NDHWC causal conv3d of the video VAE.
+ *   [ref: models/video_vae_v3/modules/causal_inflation_lib.py:62-305 (InflatedCausalConv3d:
+ *    temporal padding replaced by causal head padding / carried frames), :84-113 (Conv3d)]
+ *   x      bf16 [T, Hi, Wi, Cin]  current temporal chunk
+ *   carry  bf16 [npad, Hi, Wi, Cin] previous chunk's last (kt - st) frames, or NULL:
+ *          NULL => the head is padded with `npad` copies of frame 0 (first chunk: 2*pad_t)
+ *   w      bf16 [cout_pad, kt, kh, kw, Cin]  (cout_pad = round_up(Cout,128), extra rows zero)
+ *   y      bf16 [To, Ho, Wo, Cout],  To = (T + npad - kt)/st + 1, Ho = (Hi + pad_h0 + pad_h1 - kh)/sh + 1 ...
+ *   resid  optional bf16 [To,Ho,Wo,Cout] added after bias (ResnetBlock3D skip, attn_video_vae.py:360)
+ *   Cin % 64 == 0 (small-Cin layers go through svr2_im2col3d + svr2_gemm).
+ */
+typedef struct svr2_conv3d_desc {
+    const void* x;
+    const void* carry;
+    const void* w;
+    const float* bias;
+    const void* resid;
+    void* y;
+    int32_t T, Hi, Wi, Cin, Cout;
+    int32_t kt, kh, kw, st, sh, sw;
+    int32_t npad;             /* causal head frames (carry frames or replicas of frame 0) */
+    int32_t pad_h0, pad_w0;   /* zero padding before; padding after is implied by Ho/Wo */
+    int32_t To, Ho, Wo;
+    const void* zero_page;
+} svr2_conv3d_desc;
+
+int svr2_conv3d(const svr2_conv3d_desc* d, void* stream);
+
+/* Explicit im2col for the small-Cin causal convs (Cin = 3 or 16): col[M, kpad] with
+ * k = ((kt*kh+ky)*kw+kx)*Cin + c, zero padded to kpad (multiple of 64). */
+int svr2_im2col3d(const svr2_conv3d_desc* d, void* col, int64_t kpad, void* stream);
+
+/* ------------------------------------------------------------------ norms / modulation
+ * y = x * rsqrt(mean(x^2) + eps) * scale + shift   per row; scale/shift fp32 [dim] (shift may be NULL).
+ * Fuses CustomRMSNorm (no affine) with AdaSingle mode 'in' whose per-channel factors are constants at
+ * inference [ref: models/dit_3b/normalization.py:88-109, modulation.py:110-111,
+ *            nablocks/mmsr_block.py:108-110,115-123, nadit.py:234-244]. dim % 8 == 0, dim <= 8192. */
+int svr2_rmsnorm_mod(const void* x, void* y, const float* scale, const float* shift,
+                     int64_t rows, int32_t dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------ attention preparation
+ * Builds window-ordered Q,K,V for the joint window attention from the fused qkv projections:
+ *   - gathers the video rows of every window (window partition) and appends the text rows
+ *     to every window          [ref: models/dit_3b/na.py:228-229,386-393; mmattn.py:195-217]
+ *   - per-head RMSNorm of q,k with weight [ref: mmattn.py:207-208]
+ *   - rotary embedding in fp32, window-local video coordinates (Lt+t, h, w), text token p at (p,p,p)
+ *     [ref: models/dit_3b/rope.py:118-126,171-173]  (rope_mode 1 = 3B 'lang' mm-rope, 2 = 7B 'pixel'
+ *     video-only rope with per-position angles, 0 = none)
+ *   qkv_vid [L, 3*H*D], qkv_txt [Lt, 3*H*D]  (layout (o h d), mmattn.py:201-202)
+ *   src_row [S]: >= 0 video row, < 0 text row (-1 - j);   pos [S*3] int32 (t,h,w) rope coordinates
+ *   q,k,v out: [S, H, D].  D must be 128.
+ *   rope_cos/rope_sin: fp32 [max_pos, nfreq] tables (3B: nfreq = 21), or per-position [S, 3*nfreq] (7B)
+ */
+typedef struct svr2_qkv_prep_desc {
+    const void* qkv_vid;
+    const void* qkv_txt;
+    const int32_t* src_row;
+    const int32_t* pos;
+    const float* qn_vid; const float* kn_vid; /* [D] */
+    const float* qn_txt; const float* kn_txt;
+    const float* rope_cos; const float* rope_sin;
+    void* q; void* k; void* v;
+    int64_t S;
+    int32_t H, D, nfreq, max_pos, rope_mode;
+    float eps;
+} svr2_qkv_prep_desc;
+
+int svr2_qkv_prep(const svr2_qkv_prep_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ varlen window attention
+ * out[s, h, :] = softmax(q[s,h,:] . k[seq(s),h,:]^T / sqrt(D)) v[seq(s),h,:], non-causal, per sequence.
+ * Replaces the per-window SDPA loop / flash_attn_varlen_func
+ *   [ref: models/dit_3b/attention.py:24-61,65-92,138-157].
+ *   q,k,v,out bf16 [S, H, 128];  cu_seqlens int32 [nseq+1];
+ *   tile_seq/tile_q0 int32 [ntiles]: sequence id and first query row (multiple of 128 within the
+ *   sequence) of every 128-query tile (host-built work list).
+ */
+int svr2_window_attn(const void* q, const void* k, const void* v, void* out,
+                     const int32_t* cu_seqlens, const int32_t* tile_seq, const int32_t* tile_q0,
+                     int32_t ntiles, int32_t H, int32_t D, float scale, void* stream);
+
+/* Mean over windows of the replicated text rows [ref: models/dit_3b/na.py:396-417]:
+ * out[j, :] = mean_w attn[txt_row0[w] + j, :],  attn bf16 [S, dim]. */
+int svr2_txt_mean(const void* attn, const int32_t* txt_row0, int32_t nwin, int32_t Lt, int32_t dim,
+                  void* out, void* stream);
+
+/* ------------------------------------------------------------------ patch in / one-step endpoint
+ * rows[L, kpad] = patchify(cat[noise, latent, 1]) with patch (1,2,2), feature order (h w c), zero padded
+ * to kpad [ref: core/infer.py:54-78,340; models/dit_3b/patch/patch_v1.py:86-93].
+ * noise, latent: bf16 [T, H, W, C]. */
+int svr2_patch_in(const void* noise, const void* latent, void* rows, int32_t T, int32_t H, int32_t W,
+                  int32_t C, int32_t kpad, void* stream);
+/* x0[T,H,W,C] = noise - unpatchify(pred[L, 4*C])
+ * [ref: patch_v1.py:119-124; common/diffusion/schedules/base.py:108-110 (v_lerp endpoint at t=T)]. */
+int svr2_patch_out_x0(const void* pred, int64_t ldp, const void* noise, void* x0, int32_t T, int32_t H,
+                      int32_t W, int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDVR2_HIP_H */

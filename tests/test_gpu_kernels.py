@@ -1,0 +1,251 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes).
+
+Reference = fp32 PyTorch on the CPU applied to the SAME bf16-rounded inputs (floating-point kernels),
+or the oracle's functions (oracle/seedvr2_ref).  Tolerance: bf16 output rounding (2^-8 relative) plus
+accumulation-order noise -> |d| <= 1.6e-2*rms(ref) + 1.6e-2*|ref| unless a test states otherwise.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests_support import assert_close, bf
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_bf16(x, gpu):
+    return x.to(gpu).to(torch.bfloat16).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 200, 192), (128, 128, 64), (1000, 2560, 2560), (58, 7680, 256), (129, 64, 6912)])
+def test_gemm_bias(pkg, gpu, M, N, K):
+    hip = pkg.hip
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, bias=b.to(gpu))
+    assert_close(out, a @ w.T + b, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_gather_gate_res(pkg, gpu):
+    hip = pkg.hip
+    M, N, K, S = 700, 256, 256, 900
+    a, w = rnd(S, K, seed=4), rnd(N, K, seed=5, scale=1 / 16)
+    bias, gate, res = rnd(N, seed=6), rnd(N, seed=7), rnd(M, N, seed=8)
+    rows = torch.randperm(S, generator=torch.Generator().manual_seed(9))[:M].to(torch.int32)
+    out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, epilogue=hip.EPI_GATE_RES, bias=bias.to(gpu),
+                   gate=gate.to(gpu), resid=dev_bf16(res, gpu), a_rows=rows.to(gpu), m=M)
+    ref = res + gate * (a[rows.long()] @ w.T + bias)
+    assert_close(out, ref, "gemm gather+gate+res")
+
+
+def test_gemm_swiglu(pkg, gpu):
+    hip = pkg.hip
+    M, Hd, K = 333, 192, 128
+    a, wg, wi = rnd(M, K, seed=10), rnd(Hd, K, seed=11, scale=0.1), rnd(Hd, K, seed=12, scale=0.1)
+    wcat = hip.pad_weight(hip.interleave_swiglu(wg, wi).to(gpu))
+    out = hip.gemm(dev_bf16(a, gpu), wcat, 2 * Hd, epilogue=hip.EPI_SWIGLU)
+    assert tuple(out.shape) == (M, Hd)
+    assert_close(out, F.silu(a @ wg.T) * (a @ wi.T), "gemm swiglu")
+
+
+@pytest.mark.parametrize("tz,drop", [(1, False), (2, False), (2, True)])
+def test_gemm_pixshuf(pkg, gpu, tz, drop):
+    """Upsample3D: 1x1x1 conv then 'b (x y z c) f h w -> b c (f z)(h x)(w y)' (+ remove_head)."""
+    hip = pkg.hip
+    Fr, Hh, Ww, Cc = 3, 6, 10, 64
+    r = 4 * tz
+    x, w, b = rnd(Fr, Hh, Ww, Cc, seed=13), rnd(Cc * r, Cc, seed=14, scale=1 / 8), rnd(Cc * r, seed=15)
+    out = hip.gemm(dev_bf16(x.reshape(-1, Cc), gpu), hip.pad_weight(w.to(gpu)), Cc * r, epilogue=hip.EPI_PIXSHUF3D,
+                   bias=b.to(gpu), pixshuf=(Fr, Hh, Ww, Cc, tz, drop))
+    y = (x.reshape(-1, Cc) @ w.T + b).reshape(Fr, Hh, Ww, 2, 2, tz, Cc)  # f h w x y z c
+    ref = y.permute(0, 5, 1, 3, 2, 4, 6).reshape(Fr * tz, Hh * 2, Ww * 2, Cc)
+    if drop:
+        ref = torch.cat((ref[:1], ref[2:]), dim=0)
+    assert_close(out, ref, f"gemm pixshuf tz={tz} drop={drop}")
+
+
+# ----------------------------------------------------------------------------------------------- conv3d
+def conv_ref(x, w, b, k, s, npad, pad_hw, carry):
+    """x [T,H,W,Cin] fp32, w [Cout,kt,kh,kw,Cin]; causal head = carry frames or replicas of frame 0."""
+    head = carry if carry is not None else x[:1].expand(npad, -1, -1, -1)
+    xp = torch.cat((head, x), dim=0) if npad > 0 else x
+    xp = xp.permute(3, 0, 1, 2)[None]  # 1 C T H W
+    xp = F.pad(xp, (pad_hw[2], pad_hw[3], pad_hw[0], pad_hw[1]))
+    y = F.conv3d(xp, w.permute(0, 4, 1, 2, 3).contiguous(), b, stride=s)
+    return y[0].permute(1, 2, 3, 0)
+
+
+CONV_CASES = [
+    # T, H, W, Cin, Cout, k, s, npad, pad_hw, with_carry, resid
+    (3, 12, 20, 64, 128, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), False, False),
+    (4, 12, 20, 128, 64, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), True, True),
+    (5, 13, 21, 64, 64, (1, 3, 3), (1, 2, 2), 0, (0, 1, 0, 1), False, False),   # spatial-only downsample, pad right/bottom
+    (5, 12, 20, 64, 64, (3, 3, 3), (2, 2, 2), 2, (0, 1, 0, 1), False, False),   # space+time downsample, first chunk
+    (4, 12, 20, 64, 64, (3, 3, 3), (2, 2, 2), 1, (0, 1, 0, 1), True, False),    # ... later chunk with 1 carried frame
+    (2, 9, 7, 128, 256, (1, 1, 1), (1, 1, 1), 0, (0, 0, 0, 0), False, False),   # 1x1x1 shortcut
+    (1, 16, 16, 64, 16, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), False, False),   # small Cout
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d(pkg, gpu, case):
+    hip = pkg.hip
+    T, H, W, Cin, Cout, k, s, npad, pad_hw, with_carry, with_res = case
+    x = rnd(T, H, W, Cin, seed=20)
+    w = rnd(Cout, *k, Cin, seed=21, scale=1 / math.sqrt(Cin * k[0] * k[1] * k[2]))
+    b = rnd(Cout, seed=22)
+    carry = rnd(npad, H, W, Cin, seed=23) if with_carry else None
+    ref = conv_ref(x, w, b, k, s, npad, pad_hw, carry)
+    res = rnd(*ref.shape, seed=24) if with_res else None
+    if with_res:
+        ref = ref + res
+    out = hip.conv3d(dev_bf16(x, gpu), hip.pad_weight(w.reshape(Cout, -1).to(gpu)), Cout, k, s, npad=npad,
+                     pad_hw=pad_hw, carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
+                     resid=None if res is None else dev_bf16(res, gpu))
+    assert_close(out, ref, f"conv3d {case}")
+
+
+@pytest.mark.parametrize("Cin,with_carry", [(3, False), (16, True)])
+def test_im2col_gemm_small_cin(pkg, gpu, Cin, with_carry):
+    hip = pkg.hip
+    T, H, W, Cout, k, s, npad, pad_hw = 3, 10, 14, 128, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1)
+    x = rnd(T, H, W, Cin, seed=30)
+    w = rnd(Cout, *k, Cin, seed=31, scale=0.2)
+    b = rnd(Cout, seed=32)
+    carry = rnd(npad, H, W, Cin, seed=33) if with_carry else None
+    kreal = 27 * Cin
+    kpad = (kreal + 63) // 64 * 64
+    col = hip.im2col3d(dev_bf16(x, gpu), k, s, npad=npad, pad_hw=pad_hw,
+                       carry=None if carry is None else dev_bf16(carry, gpu), kpad=kpad)
+    out = hip.gemm(col, hip.pad_weight(w.reshape(Cout, -1).to(gpu), kpad), Cout, bias=b.to(gpu))
+    ref = conv_ref(x, w, b, k, s, npad, pad_hw, carry).reshape(-1, Cout)
+    assert_close(out, ref, f"im2col+gemm Cin={Cin}")
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,dim,with_shift", [(77, 2560, True), (5, 256, False), (58, 3072, True), (9, 8192, True)])
+def test_rmsnorm_mod(pkg, gpu, rows, dim, with_shift):
+    hip = pkg.hip
+    x, sc, sh = rnd(rows, dim, seed=40, scale=3.0), rnd(dim, seed=41) + 1, rnd(dim, seed=42)
+    out = hip.rmsnorm_mod(dev_bf16(x, gpu), sc.to(gpu), sh.to(gpu) if with_shift else None, 1e-5)
+    ref = x / torch.sqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * sc + (sh if with_shift else 0)
+    assert_close(out, ref, "rmsnorm_mod")
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, lens):
+    out, off = [], 0
+    for n in lens:
+        qs, ks, vs = (t[off:off + n].permute(1, 0, 2) for t in (q, k, v))
+        pr = torch.softmax((qs @ ks.transpose(1, 2)) / math.sqrt(q.shape[-1]), dim=-1)
+        out.append((pr @ vs).permute(1, 0, 2))
+        off += n
+    return torch.cat(out)
+
+
+@pytest.mark.parametrize("lens,H", [([5, 71, 128, 1], 2), ([463, 868, 135, 64, 129], 3), ([2083], 1)])
+def test_window_attn(pkg, gpu, lens, H):
+    hip = pkg.hip
+    S = sum(lens)
+    q, k, v = rnd(S, H, 128, seed=50), rnd(S, H, 128, seed=51), rnd(S, H, 128, seed=52)
+    # spike one key against one query so the running max jumps mid-sequence (rescale path)
+    if lens[0] >= 463:
+        k[300] = q[10] * 3.0
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    tseq, tq0 = [], []
+    for i, n in enumerate(lens):
+        for q0 in range(0, n, 128):
+            tseq.append(i); tq0.append(q0)
+    up = lambda a: torch.tensor(a, dtype=torch.int32, device=gpu)
+    out = hip.window_attn(dev_bf16(q, gpu), dev_bf16(k, gpu), dev_bf16(v, gpu), up(cu), up(tseq), up(tq0),
+                          1 / math.sqrt(128))
+    assert_close(out, attn_ref(q, k, v, lens), f"window_attn {lens}", rtol=2e-2, atol_rel=2e-2)
+
+
+def test_qkv_prep_and_txt_mean(pkg, gpu):
+    """Window gather + per-head RMSNorm + 3B mm-rope vs the oracle's pieces."""
+    from seedvr2_ref import dit as odit, rope as orope, windows as owin
+    hip, W = pkg.hip, pkg.windows
+    H, D, Lt = 2, 128, 58
+    grid = (3, 10, 12)
+    L = grid[0] * grid[1] * grid[2]
+    qkv_v, qkv_t = rnd(L, 3 * H * D, seed=60), rnd(Lt, 3 * H * D, seed=61)
+    nq, nk, nqt, nkt = (rnd(D, seed=62 + i) * 0.1 + 1 for i in range(4))
+    for method in (W.REGULAR, W.SHIFTED):
+        pl = W.plan(grid, method, Lt)
+        fr = orope.lang_freqs(D // 3)
+        ang = torch.arange(256, dtype=torch.float32)[:, None] * fr[None]
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+        out = hip.qkv_prep(dev_bf16(qkv_v, gpu), dev_bf16(qkv_t, gpu), up(pl.src_row), up(pl.pos), nq.to(gpu),
+                           nk.to(gpu), nqt.to(gpu), nkt.to(gpu), ang.cos().contiguous().to(gpu),
+                           ang.sin().contiguous().to(gpu), H, 1, 1e-5).float().cpu()
+        # oracle: per window
+        boxes = owin.windows_for(method, grid)
+        idx, lens, shapes = owin.window_token_index(grid, boxes)
+        qv, kv, vv = (qkv_v.reshape(L, 3, H, D)[:, i] for i in range(3))
+        qt, kt, vt = (qkv_t.reshape(Lt, 3, H, D)[:, i] for i in range(3))
+        qv, kv = odit.rms_norm(qv, 1e-5, nq), odit.rms_norm(kv, 1e-5, nk)
+        qt, kt = odit.rms_norm(qt, 1e-5, nqt), odit.rms_norm(kt, 1e-5, nkt)
+        ref_q, ref_k, ref_v, off = [], [], [], 0
+        for n, shp in zip(lens.tolist(), shapes.tolist()):
+            sel = torch.from_numpy(idx[off:off + n]); off += n
+            av, at = orope.mm_window_angles_3b(shp, Lt, D)
+            ref_q += [orope.rotate_interleaved(qv[sel], av[:, None]), orope.rotate_interleaved(qt, at[:, None])]
+            ref_k += [orope.rotate_interleaved(kv[sel], av[:, None]), orope.rotate_interleaved(kt, at[:, None])]
+            ref_v += [vv[sel], vt]
+        assert_close(out[0], torch.cat(ref_q), f"qkv_prep q {method}")
+        assert_close(out[1], torch.cat(ref_k), f"qkv_prep k {method}")
+        assert_close(out[2], torch.cat(ref_v), f"qkv_prep v {method}", rtol=0, atol_rel=0)
+        # text mean over windows
+        att = rnd(pl.total, 256, seed=70)
+        tm = hip.txt_mean(dev_bf16(att, gpu), up(pl.txt_row0), Lt)
+        ref_tm = torch.stack([att[r0:r0 + Lt] for r0 in pl.txt_row0.tolist()], dim=1).mean(1)
+        assert_close(tm, ref_tm, "txt_mean")
+
+
+def test_patch_in_out(pkg, gpu):
+    from seedvr2_ref import dit as odit
+    hip = pkg.hip
+    T, H, W, Cc = 2, 6, 8, 16
+    noise, latent = rnd(T, H, W, Cc, seed=80), rnd(T, H, W, Cc, seed=81)
+    rows = hip.patch_in(dev_bf16(noise, gpu), dev_bf16(latent, gpu), 192).float().cpu()
+    vid = torch.cat((noise, latent, torch.ones(T, H, W, 1)), dim=-1).reshape(-1, 33)
+    ref = odit.patch_in(vid, (T, H, W), (1, 2, 2))
+    assert torch.equal(rows[:, :132], ref) and rows[:, 132:].abs().max() == 0
+    pred = rnd(T * (H // 2) * (W // 2), 64, seed=82)
+    x0 = hip.patch_out_x0(dev_bf16(pred, gpu), dev_bf16(noise, gpu))
+    ref0 = noise.reshape(-1, Cc) - odit.patch_out(pred, (T, H // 2, W // 2), (1, 2, 2), Cc)
+    assert_close(x0.reshape(-1, Cc), ref0, "patch_out_x0", rtol=8e-3, atol_rel=8e-3)
+
+
+# ----------------------------------------------------------------------------------------------- DiT
+@pytest.mark.parametrize("grid_thw", [(2, 16, 24), (1, 32, 32), (3, 20, 36)])
+def test_dit_one_step_vs_oracle(pkg, gpu, grid_thw):
+    """Whole NaDiT one-step (3 layers: separate-weights layer, shared layer, last layer) vs the fp32 oracle.
+    Tolerance: the bf16 oracle itself deviates from the fp32 oracle by err_bf16; require err_hip <= 2*err_bf16."""
+    from seedvr2_ref import dit as odit
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=3, mm_layers=1, txt_in_dim=64, mlp_multiple_of=64)
+    ocfg = odit.DiTConfig(**kw)
+    p = {k: bf(v) for k, v in odit.synthetic_params(ocfg, 3).items()}
+    model = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(**kw), p, gpu)
+    T, H, W = grid_thw
+    noise, latent, txt = rnd(T, H, W, 16, seed=90), rnd(T, H, W, 16, seed=91), rnd(58, 64, seed=92)
+    got = model.one_step(dev_bf16(noise, gpu), dev_bf16(latent, gpu), txt.to(gpu)).float().cpu()
+    ref32 = odit.one_step_sr(p, ocfg, latent, noise, txt, torch.float32)
+    ref16 = odit.one_step_sr(p, ocfg, latent, noise, txt, torch.bfloat16).float()
+    rms = ref32.pow(2).mean().sqrt()
+    e_hip = (got - ref32).pow(2).mean().sqrt() / rms
+    e_b16 = (ref16 - ref32).pow(2).mean().sqrt() / rms
+    print(f"DiT {grid_thw}: rel-rms err hip={e_hip:.4e} bf16-oracle={e_b16:.4e}")
+    assert torch.isfinite(got).all()
+    assert e_hip <= 2.0 * e_b16 + 1e-3, (e_hip, e_b16)
+    assert_close(got, ref32, "dit one_step", rtol=5e-2, atol_rel=5e-2)

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual HIP kernels at the shapes of the named configs (GPU box only).
+Prints one line per kernel: time, algorithmic TFLOP/s or GB/s."""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+hip = pkg.hip
+dev = torch.device("cuda:0")
+hip.device_check(0)
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def rb(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
+
+
+def bench_gemm(M, N, K, epi="bias"):
+    a = rb(M, K)
+    w = hip.pad_weight(rb(N, K, scale=1 / math.sqrt(K)))
+    out = torch.empty(M, N if epi != "swiglu" else N // 2, dtype=torch.bfloat16, device=dev)
+    if epi == "bias":
+        fn = lambda: hip.gemm(a, w, N, out)
+    elif epi == "swiglu":
+        fn = lambda: hip.gemm(a, w, N, out, epilogue=hip.EPI_SWIGLU)
+    else:
+        res, gate = rb(M, N), torch.randn(N, device=dev)
+        fn = lambda: hip.gemm(a, w, N, out, epilogue=hip.EPI_GATE_RES, gate=gate, resid=res)
+    t = timeit(fn)
+    print(f"gemm[{epi}] M={M} N={N} K={K}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s", flush=True)
+
+
+def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3)):
+    x = rb(T, H, W, Cin)
+    w = hip.pad_weight(rb(Cout, k[0] * k[1] * k[2] * Cin, scale=0.02))
+    b = torch.zeros(Cout, device=dev)
+    out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out)
+    t = timeit(fn, iters=5, warm=1)
+    fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
+    print(f"conv3d T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
+
+
+def bench_attn(grid, method, H=20):
+    pl = pkg.windows.plan(grid, method, 58)
+    S = pl.total
+    q, k, v = rb(S, H, 128), rb(S, H, 128), rb(S, H, 128)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cu, ts, tq = up(pl.cu_seqlens), up(pl.tile_seq), up(pl.tile_q0)
+    out = torch.empty_like(q)
+    fn = lambda: hip.window_attn(q, k, v, cu, ts, tq, 1 / math.sqrt(128), out)
+    t = timeit(fn, iters=5, warm=1)
+    lens = np.diff(pl.cu_seqlens).astype(np.float64)
+    fl = 4 * 128 * (lens ** 2).sum() * H
+    print(f"window_attn grid={grid} {method[:7]} S={S} nwin={pl.nwin}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
+
+
+def bench_norm(rows, dim):
+    x = rb(rows, dim)
+    sc, sh = torch.randn(dim, device=dev), torch.randn(dim, device=dev)
+    out = torch.empty_like(x)
+    t = timeit(lambda: hip.rmsnorm_mod(x, sc, sh, 1e-5, out))
+    print(f"rmsnorm_mod {rows}x{dim}: {t*1e3:.3f} ms  {rows*dim*4/t/1e9:.0f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "conv", "attn", "norm"]
+    if "gemm" in which:
+        for M in (24480, 162000):
+            bench_gemm(M, 7680, 2560)
+            bench_gemm(M, 2560, 2560, "gate")
+            bench_gemm(M, 13824, 2560, "swiglu")
+            bench_gemm(M, 2560, 6912, "gate")
+        bench_gemm(8192, 8192, 8192)
+    if "conv" in which:
+        bench_conv(5, 136, 240, 512, 512)
+        bench_conv(5, 272, 480, 512, 512)
+        bench_conv(5, 544, 960, 256, 256)
+        bench_conv(5, 1088, 1920, 128, 128)
+        bench_conv(4, 2160, 3840, 128, 128)
+    if "attn" in which:
+        bench_attn((3, 68, 120), pkg.windows.REGULAR)
+        bench_attn((5, 135, 240), pkg.windows.REGULAR)
+        bench_attn((5, 135, 240), pkg.windows.SHIFTED)
+    if "norm" in which:
+        bench_norm(162000, 2560)
