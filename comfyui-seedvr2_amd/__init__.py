@@ -5,8 +5,12 @@ Directory name follows the ComfyUI custom-node convention (hyphenated); import i
   hip      ctypes binding of libseedvr2_hip.so (the C ABI, include/seedvr2_hip.h)
   windows  host-side window geometry / index tables of the swin attention
   dit      NaDiT runner on the HIP kernels
+  vae      causal 3-D video VAE runner on the HIP kernels
+  pipeline transform -> encode -> one-step DiT -> decode -> blend (the four generation phases)
 """
 
 from . import hip  # noqa: F401
 from . import windows  # noqa: F401
 from . import dit  # noqa: F401
+from . import vae  # noqa: F401
+from . import pipeline  # noqa: F401

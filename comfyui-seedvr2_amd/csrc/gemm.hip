@@ -344,7 +344,8 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
     SVR2_CHECK(d->Cin > 0 && d->Cin % BK == 0, SVR2_E_SHAPE, "svr2_conv3d: Cin %% 64 != 0 (Cin=%d); use svr2_im2col3d",
                d->Cin);
-    SVR2_CHECK(d->Cout > 0 && d->Cout % 8 == 0, SVR2_E_SHAPE, "svr2_conv3d: Cout %% 8 != 0 (Cout=%d)", d->Cout);
+    SVR2_CHECK(d->Cout > 0 && (d->Cout % 8 == 0 || d->resid == nullptr), SVR2_E_SHAPE,
+               "svr2_conv3d: Cout %% 8 != 0 needs resid == NULL (Cout=%d)", d->Cout);
     SVR2_CHECK(d->kt >= 1 && d->kh >= 1 && d->kw >= 1 && d->st >= 1 && d->sh >= 1 && d->sw >= 1 && d->npad >= 0,
                SVR2_E_SHAPE, "svr2_conv3d: bad kernel/stride");
     SVR2_CHECK(d->T >= 1 && (d->T + d->npad - d->kt) >= 0 && d->To == (d->T + d->npad - d->kt) / d->st + 1,

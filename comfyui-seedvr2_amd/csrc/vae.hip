@@ -1,0 +1,320 @@
+// VAE-side kernels: per-frame GroupNorm (+SiLU) and the single-head d=512 spatial attention of the
+// mid block.  GroupNorm is HBM-bound (2 reads + 1 write of the activation); the attention is a flash
+// kernel on v_mfma_f32_16x16x32_bf16 in the same swapped orientation as csrc/attn.hip.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- GroupNorm statistics
+// x [F][P][C] bf16 (channels-last).  Pass 1: every workgroup reduces a strip of pixels of one frame to
+// per-channel (sum, sumsq) fp32 partials.  Pass 2: one wave per (frame, group) folds the partials in
+// fp64 and writes per-(frame, channel) affine coefficients a = rstd*gamma, b = beta - mean*rstd*gamma.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict__ x, float* __restrict__ partial,
+                                                         long long P, int C, int nblk) {
+    __shared__ float red[256 * 16];
+    const int nvec = C >> 3, ppb = 256 / nvec;
+    const int vec = threadIdx.x % nvec, prow = threadIdx.x / nvec;
+    const int f = blockIdx.y, blk = blockIdx.x;
+    const long long span = (P + nblk - 1) / nblk;
+    const long long p0 = blk * span, p1 = min(P, p0 + span);
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    if (prow < ppb) {
+        const bf16* base = x + ((long long)f * P) * C + vec * 8;
+        for (long long p = p0 + prow; p < p1; p += ppb) {
+            const bf16x8 v = *(const bf16x8*)(base + p * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = bf2f(v[e]);
+                s[e] += t;
+                ss[e] += t * t;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[threadIdx.x * 16 + e] = s[e];
+        red[threadIdx.x * 16 + 8 + e] = ss[e];
+    }
+    __syncthreads();
+    // threads [0, nvec*16): (vec, e16) pairs sum over prow
+    for (int i = threadIdx.x; i < nvec * 16; i += 256) {
+        const int v = i >> 4, e = i & 15;
+        float acc = 0.f;
+        for (int r = 0; r < ppb; ++r) acc += red[(r * nvec + v) * 16 + e];
+        // partial layout [F][nblk][2][C]
+        const int c = v * 8 + (e & 7);
+        partial[(((long long)f * nblk + blk) * 2 + (e >> 3)) * C + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ coef,
+                                                         long long P, int C, int G, int nblk, float eps) {
+    const int f = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const float* ps = partial + (((long long)f * nblk + b) * 2) * C + g * cpg;
+        for (int c = 0; c < cpg; ++c) {
+            s += (double)ps[c];
+            ss += (double)ps[C + c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    const double n = (double)P * cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = lane; c < cpg; c += 64) {
+        const int ch = g * cpg + c;
+        const float a = rstd * gamma[ch];
+        coef[((long long)f * C + ch) * 2 + 0] = a;
+        coef[((long long)f * C + ch) * 2 + 1] = beta[ch] - (float)mean * a;
+    }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ coef,
+                                                       bf16* __restrict__ y, long long P, int C, int nblk) {
+    const int nvec = C >> 3, ppb = 256 / nvec;
+    const int vec = threadIdx.x % nvec, prow = threadIdx.x / nvec;
+    if (prow >= ppb) return;
+    const int f = blockIdx.y, blk = blockIdx.x;
+    const long long span = (P + nblk - 1) / nblk;
+    const long long p0 = blk * span, p1 = min(P, p0 + span);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = coef[((long long)f * C + vec * 8 + e) * 2];
+        b[e] = coef[((long long)f * C + vec * 8 + e) * 2 + 1];
+    }
+    const long long base = ((long long)f * P) * C + vec * 8;
+    for (long long p = p0 + prow; p < p1; p += ppb) {
+        const bf16x8 v = *(const bf16x8*)(x + base + p * C);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = bf2f(v[e]) * a[e] + b[e];
+            if (SILU) t = t / (1.f + __expf(-t));
+            o[e] = f2bf(t);
+        }
+        *(bf16x8*)(y + base + p * C) = o;
+    }
+}
+
+// ----------------------------------------------------------------------------- attention, head dim 512
+constexpr int D5 = 512, QB5 = 128, KB5 = 32, NTH5 = 512;
+constexpr int KV5_BYTES = KB5 * D5 * 2;   // 32 KiB per K or V tile
+constexpr int ATT5_LDS = 4 * KV5_BYTES;   // K[2] + V[2] = 128 KiB
+
+struct Attn5Args {
+    const bf16* q; const bf16* k; const bf16* v; bf16* out;
+    long long ld, ldo;
+    int P;  // tokens per frame
+    float scale_log2;
+};
+
+__global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const long long s0 = (long long)blockIdx.y * a.P;
+    const int q0 = blockIdx.x * QB5;
+    const int len = a.P;
+
+    bf16x8 qf[16];
+    {
+        int qr = q0 + wave * 16 + l15;
+        if (qr > len - 1) qr = len - 1;
+        const bf16* qp = a.q + (s0 + qr) * a.ld + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+    }
+
+    auto issue = [&](int t, int stage) {
+        char* sK = smem + stage * KV5_BYTES;
+        char* sV = smem + (2 + stage) * KV5_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = wave * 4 + i;
+            int kr = t * KB5 + key;
+            if (kr > len - 1) kr = len - 1;
+            const long long row = (s0 + kr) * a.ld;
+            glds16(a.k + row + ((lane ^ (key & 15)) << 3), sK + key * 1024);
+            glds16(a.v + row + ((lane ^ ((key & 7) << 1)) << 3), sV + key * 1024);
+        }
+    };
+
+    f32x4 oacc[32];
+#pragma unroll
+    for (int dt = 0; dt < 32; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int tq = l15 >> 2, tp = l15 & 3;
+
+    const int nt = (len + KB5 - 1) / KB5;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * KV5_BYTES;
+        const char* sV = smem + (2 + (t & 1)) * KV5_BYTES;
+
+        f32x4 sacc[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            sacc[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int key = k2 * 16 + l15;
+            const char* kp = sK + key * 1024;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kp + (((4 * ks + kq) ^ (key & 15)) << 4));
+                sacc[k2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
+            }
+        }
+        // lane holds keys 16*k2 + 4*kq + r of query l15
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = t * KB5 + k2 * 16 + 4 * kq + r;
+                float sv = sacc[k2][r] * a.scale_log2;
+                sv = kidx < len ? sv : -INFINITY;
+                sacc[k2][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[k2][r] - m_new);
+                psum += p;
+                pf[k2 * 4 + r] = f2bf(p);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 32; ++dt) oacc[dt] *= alpha;
+
+        const int key0 = 4 * kq + tq;
+        const char* vrow = sV + key0 * 1024 + (tp & 1) * 8;
+        const int vswz = (key0 & 7) << 1;
+#pragma unroll
+        for (int dt = 0; dt < 32; ++dt) {
+            const int chunk = dt * 2 + (tp >> 1);
+            const char* p0 = vrow + ((chunk ^ vswz) << 4);
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 16 * 1024));
+            bf16x8 vf;
+            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + wave * 16 + l15;
+    if (qr < len) {
+        bf16* op = a.out + (s0 + qr) * a.ldo + 4 * kq;
+#pragma unroll
+        for (int dt = 0; dt < 32; ++dt) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[dt][e] * inv);
+            *(bf16x4*)(op + dt * 16) = o;
+        }
+    }
+}
+
+inline int gn_blocks(long long P, int C) {
+    const int ppb = 256 / (C >> 3);
+    long long nb = (P + (long long)ppb * 8 - 1) / ((long long)ppb * 8);
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    return (int)nb;
+}
+
+}  // namespace
+
+/* workspace floats needed by svr2_groupnorm_stats */
+extern "C" int64_t svr2_groupnorm_ws_floats(int32_t F, int64_t P, int32_t C) {
+    if (F <= 0 || P <= 0 || C <= 0 || C % 8) return 0;
+    return (int64_t)F * gn_blocks(P, C) * 2 * C;
+}
+
+extern "C" int svr2_groupnorm_stats(const void* x, int32_t F, int64_t P, int32_t C, int32_t G, float eps,
+                                    const float* gamma, const float* beta, float* workspace, float* coef,
+                                    void* stream) {
+    SVR2_CHECK(x && gamma && beta && workspace && coef, SVR2_E_ARG, "svr2_groupnorm_stats: null pointer");
+    SVR2_CHECK(F > 0 && F <= 65535 && P > 0 && C >= 8 && C <= 2048 && C % 8 == 0 && 256 % (C / 8) == 0 && G > 0 &&
+                   C % G == 0,
+               SVR2_E_SHAPE, "svr2_groupnorm_stats: unsupported shape F=%d C=%d G=%d", F, C, G);
+    SVR2_CHECK(aligned16(x), SVR2_E_ALIGN, "svr2_groupnorm_stats: x must be 16-byte aligned");
+    const int nblk = gn_blocks(P, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, workspace, (long long)P, C,
+                       nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, F), dim3(64), 0, s, workspace, gamma, beta, coef, (long long)P, C, G,
+                       nblk, eps);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_groupnorm_apply(const void* x, const float* coef, void* y, int32_t F, int64_t P, int32_t C,
+                                    int32_t silu, void* stream) {
+    SVR2_CHECK(x && coef && y, SVR2_E_ARG, "svr2_groupnorm_apply: null pointer");
+    SVR2_CHECK(F > 0 && F <= 65535 && P > 0 && C >= 8 && C <= 2048 && C % 8 == 0 && 256 % (C / 8) == 0, SVR2_E_SHAPE,
+               "svr2_groupnorm_apply: unsupported shape");
+    SVR2_CHECK(aligned16(x) && aligned16(y), SVR2_E_ALIGN, "svr2_groupnorm_apply: alignment");
+    const int nblk = gn_blocks(P, C);
+    hipStream_t s = (hipStream_t)stream;
+    if (silu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, coef, (bf16*)y,
+                           (long long)P, C, nblk);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, coef, (bf16*)y,
+                           (long long)P, C, nblk);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo,
+                              int32_t frames, int32_t P, float scale, void* stream) {
+    SVR2_CHECK(q && k && v && out, SVR2_E_ARG, "svr2_attn_d512: null pointer");
+    SVR2_CHECK(frames > 0 && frames <= 65535 && P > 0 && ld >= D5 && ldo >= D5 && ld % 8 == 0 && ldo % 8 == 0,
+               SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
+    SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
+               "svr2_attn_d512: pointers must be 16-byte aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_d512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ATT5_LDS);
+        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "svr2_attn_d512: cannot reserve %d bytes of LDS", ATT5_LDS);
+        attr_set = true;
+    }
+    Attn5Args a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
+    a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_d512_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream,
+                       a);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}

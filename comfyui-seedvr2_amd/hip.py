@@ -69,7 +69,8 @@ _zero_pages = {}
 EXPORTS = [
     "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
     "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_txt_mean", "svr2_patch_in",
-    "svr2_patch_out_x0",
+    "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
+    "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
 ]
 
 
@@ -85,7 +86,7 @@ def lib() -> C.CDLL:
         _lib.svr2_last_error.restype = C.c_char_p
         for name in EXPORTS:
             if name != "svr2_last_error" and hasattr(_lib, name):
-                getattr(_lib, name).restype = C.c_int
+                getattr(_lib, name).restype = C.c_int64 if name == "svr2_groupnorm_ws_floats" else C.c_int
     return _lib
 
 
@@ -366,3 +367,88 @@ def patch_out_x0(pred: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     _check(lib().svr2_patch_out_x0(_p(pred), C.c_int64(pred.stride(0)), _p(noise), _p(x0), C.c_int32(T),
                                    C.c_int32(H), C.c_int32(W), C.c_int32(Cc), _stream()), "svr2_patch_out_x0")
     return x0
+
+
+# ----------------------------------------------------------------------------------------- VAE kernels
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                   silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-frame GroupNorm (+SiLU) of a channels-last activation x [F, H, W, C]."""
+    _bf16c(x, "groupnorm.x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise HipError("groupnorm: x must be contiguous [F,H,W,C]")
+    Fr, H, W, Cc = x.shape
+    _f32c(gamma, "groupnorm.gamma", Cc); _f32c(beta, "groupnorm.beta", Cc)
+    P = H * W
+    nws = lib().svr2_groupnorm_ws_floats(C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc))
+    if nws <= 0:
+        raise HipError(f"groupnorm: unsupported shape {tuple(x.shape)}")
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    coef = torch.empty(Fr, Cc, 2, dtype=torch.float32, device=x.device)
+    _check(lib().svr2_groupnorm_stats(_p(x), C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc), C.c_int32(groups),
+                                      C.c_float(eps), _p(gamma), _p(beta), _p(ws), _p(coef), _stream()),
+           "svr2_groupnorm_stats")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().svr2_groupnorm_apply(_p(x), _p(coef), _p(out), C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc),
+                                      C.c_int32(1 if silu else 0), _stream()), "svr2_groupnorm_apply")
+    return out
+
+
+def attn_d512(qkv: torch.Tensor, frames: int, tokens: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv bf16 [frames*tokens, 1536] (q | k | v) -> out [frames*tokens, 512]."""
+    _bf16c(qkv, "attn_d512.qkv")
+    if qkv.dim() != 2 or qkv.shape[1] != 1536 or qkv.shape[0] != frames * tokens or not qkv.is_contiguous():
+        raise HipError("attn_d512: qkv must be contiguous [frames*tokens, 1536]")
+    if out is None:
+        out = torch.empty(frames * tokens, 512, dtype=torch.bfloat16, device=qkv.device)
+    base = qkv.data_ptr()
+    _check(lib().svr2_attn_d512(C.c_void_p(base), C.c_void_p(base + 1024), C.c_void_p(base + 2048), C.c_int64(1536),
+                                _p(out), C.c_int64(512), C.c_int32(frames), C.c_int32(tokens),
+                                C.c_float(1.0 / (512 ** 0.5)), _stream()), "svr2_attn_d512")
+    return out
+
+
+def resize_pad_normalize(frames: torch.Tensor, taps, hp: int, wp: int) -> torch.Tensor:
+    """frames bf16 [T,Hin,Win,3] in [0,1] -> bf16 [T,hp,wp,3] model input; taps from pipeline.resize_taps()."""
+    _bf16c(frames, "resize.frames")
+    if frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_contiguous():
+        raise HipError("resize: frames must be contiguous [T,H,W,3]")
+    T, Hin, Win, _ = frames.shape
+    wy, ymin, ycnt, wx, xmin, xcnt = taps
+    Hout, KY = wy.shape
+    Wout, KX = wx.shape
+    if int((ymin + ycnt).max()) > Hin or int((xmin + xcnt).max()) > Win or int(ycnt.max()) > KY or int(xcnt.max()) > KX:
+        raise HipError("resize: tap table reaches outside the input")
+    if hp < Hout or wp < Wout:
+        raise HipError("resize: padded size smaller than the resized image")
+    out = torch.empty(T, hp, wp, 3, dtype=torch.bfloat16, device=frames.device)
+    _check(lib().svr2_resize_pad_normalize(_p(frames), _p(out), _p(wy), _p(ymin), _p(ycnt), _p(wx), _p(xmin), _p(xcnt),
+                                           C.c_int32(T), C.c_int32(Hin), C.c_int32(Win), C.c_int32(Hout),
+                                           C.c_int32(Wout), C.c_int32(hp), C.c_int32(wp), C.c_int32(KY), C.c_int32(KX),
+                                           _stream()), "svr2_resize_pad_normalize")
+    return out
+
+
+def blend_overlap(prev_tail: torch.Tensor, cur_head: torch.Tensor, w_prev: torch.Tensor, out: torch.Tensor):
+    _bf16c(prev_tail, "blend.prev"); _bf16c(cur_head, "blend.cur"); _bf16c(out, "blend.out")
+    ov = prev_tail.shape[0]
+    if prev_tail.shape != cur_head.shape or out.shape != prev_tail.shape or w_prev.numel() != ov:
+        raise HipError("blend: shape mismatch")
+    if not (prev_tail.is_contiguous() and cur_head.is_contiguous() and out.is_contiguous()):
+        raise HipError("blend: tensors must be contiguous")
+    _f32c(w_prev, "blend.w_prev", ov)
+    _check(lib().svr2_blend_overlap(_p(prev_tail), _p(cur_head), _p(out), _p(w_prev),
+                                    C.c_int64(prev_tail[0].numel()), C.c_int32(ov), _stream()), "svr2_blend_overlap")
+    return out
+
+
+def crop_to_unit(x: torch.Tensor, h: int, w: int, to_unit: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "crop.x")
+    if x.dim() != 4 or x.shape[3] != 3 or not x.is_contiguous() or h > x.shape[1] or w > x.shape[2]:
+        raise HipError("crop: x must be contiguous [T,Hp,Wp,3] with Hp >= h, Wp >= w")
+    if out is None:
+        out = torch.empty(x.shape[0], h, w, 3, dtype=torch.bfloat16, device=x.device)
+    _check(lib().svr2_crop_to_unit(_p(x), _p(out), C.c_int32(x.shape[0]), C.c_int32(x.shape[1]), C.c_int32(x.shape[2]),
+                                   C.c_int32(h), C.c_int32(w), C.c_int32(1 if to_unit else 0), _stream()),
+           "svr2_crop_to_unit")
+    return out

@@ -1,0 +1,209 @@
+"""Per-frame-chunk pipeline: transform -> VAE encode -> one-step DiT -> VAE decode -> blend -> [0,1].
+
+Host-side restatement of the reference's four generation phases
+[ref: src/core/generation_phases.py:171-521 (encode_all_batches), :538-801 (upscale_all_batches),
+ :802-1047 (decode_all_batches), :1049-1362 (postprocess_all_batches, color_correction='none')]
+and their helpers [ref: src/core/generation_utils.py:47-84 (transforms), :284-312 (blend),
+ :555-590 (batch params), :593-652 (temporal padding)] sized for 288 GB of HBM: every batch stays on the
+device from LR frames to the blended output (no CPU offload, no BlockSwap, no tiling).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+# ----------------------------------------------------------------------------- geometry
+def target_dims(h: int, w: int, resolution: int, max_resolution: int = 0) -> Tuple[int, int, int, int, int, int]:
+    """(resized_h, resized_w, true_h, true_w, padded_h, padded_w).
+    Shortest edge -> resolution with torchvision resize(int) semantics (long = int(res*long/short))
+    [ref: data/image/transforms/side_resize.py:36-75]; true dims rounded down to even
+    [ref: core/generation_utils.py:134-136]; processing dims padded up to x16 [ref: divisible_crop.py:43-80]."""
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = resolution, int(resolution * long_ / short)
+    rh, rw = (new_long, new_short) if w <= h else (new_short, new_long)
+    if max_resolution > 0 and max(rh, rw) > max_resolution:
+        s = max_resolution / max(rh, rw)
+        rh, rw = round(rh * s), round(rw * s)
+    th, tw = (rh // 2) * 2, (rw // 2) * 2
+    ph, pw = (rh + 15) // 16 * 16, (rw + 15) // 16 * 16
+    return rh, rw, th, tw, ph, pw
+
+
+def _cubic(x: np.ndarray, a: float = -0.5) -> np.ndarray:
+    x = np.abs(x).astype(np.float32)
+    w1 = ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0
+    w2 = (((x - 5.0) * x + 8.0) * x - 4.0) * a
+    return np.where(x < 1.0, w1, np.where(x < 2.0, w2, 0.0)).astype(np.float32)
+
+
+def aa_bicubic_taps(in_size: int, out_size: int):
+    """Separable tap table of ATen's antialiased bicubic (_upsample_bicubic2d_aa, align_corners=False):
+    support = 2*max(scale,1), weights = cubic(a=-0.5) of the (scaled) distance to the pixel centre,
+    normalised to sum 1.  (torchvision's resize(..., BICUBIC, antialias=True) lowers to this op,
+    [ref: data/image/transforms/side_resize.py:61].)  Returns (weights [out,K] f32, xmin [out], count [out])."""
+    scale = in_size / out_size
+    support = 2.0 * scale if scale >= 1.0 else 2.0
+    invscale = 1.0 / scale if scale >= 1.0 else 1.0
+    K = int(math.ceil(support)) * 2 + 1
+    wts = np.zeros((out_size, K), dtype=np.float32)
+    mins = np.zeros(out_size, dtype=np.int32)
+    cnts = np.zeros(out_size, dtype=np.int32)
+    for i in range(out_size):
+        center = np.float32(scale) * np.float32(i + 0.5)
+        xmin = max(int(center - np.float32(support) + np.float32(0.5)), 0)
+        xsize = min(int(center + np.float32(support) + np.float32(0.5)), in_size) - xmin
+        j = np.arange(xsize, dtype=np.float32)
+        w = _cubic((j + np.float32(xmin) - center + np.float32(0.5)) * np.float32(invscale))
+        tot = w.sum(dtype=np.float32)
+        if tot != 0:
+            w = w / tot
+        wts[i, :xsize] = w
+        mins[i], cnts[i] = xmin, xsize
+    return wts, mins, cnts
+
+
+# ----------------------------------------------------------------------------- temporal batching
+@dataclass
+class Batch:
+    start: int       # first source frame
+    end: int         # one past the last source frame
+    ori_len: int     # frames that are real (kept after decode)
+    index: List[int]  # source-frame index of every frame fed to the VAE (4n+1 / uniform padding applied)
+
+
+def _reversed_tail_indices(t: int, count: int) -> List[int]:
+    """Indices appended by pad_video_temporal(prepend=False) [ref: core/generation_utils.py:593-652]."""
+    if count <= 0:
+        return []
+    if count >= t:
+        rep = count - t + 1
+        return list(range(t - 1, 0, -1)) + [t - 1] * rep if t > 1 else [t - 1] * rep
+    return list(range(t - 2, t - 2 - count, -1))
+
+
+def plan_batches(total: int, batch_size: int, overlap: int, uniform: bool = False) -> Tuple[List[Batch], int]:
+    """Batch i = frames [i*step, i*step + batch_size), stop when the remainder <= overlap
+    [ref: core/generation_phases.py:267-282, 342-400]; each batch padded to 4n+1 (and to batch_size when
+    uniform) by appending reversed trailing frames [ref: :109-124].  Returns (batches, effective overlap)."""
+    step = batch_size - overlap if overlap > 0 else batch_size
+    if step <= 0:
+        step, overlap = batch_size, 0
+    out: List[Batch] = []
+    for s in range(0, total, step):
+        e = min(s + batch_size, total)
+        if s > 0 and e - s <= overlap:
+            break
+        n = e - s
+        idx = list(range(n))
+        if uniform and n < batch_size:
+            idx += [idx[j] for j in _reversed_tail_indices(len(idx), batch_size - n)]
+        t = len(idx)
+        if t % 4 != 1:
+            cnt = ((t - 1) // 4 + 1) * 4 + 1 - t
+            if cnt >= t:  # repeat-last + reversed order of pad_video_temporal's "exceeds length" branch
+                rep = cnt - t + 1
+                idx = idx + ([idx[j] for j in range(t - 1, 0, -1)] if t > 1 else []) + [idx[-1]] * rep
+            else:
+                idx = idx + [idx[j] for j in range(t - 2, t - 2 - cnt, -1)]
+        out.append(Batch(s, e, n, [s + j for j in idx]))
+    return out, overlap
+
+
+def blend_weights(overlap: int) -> torch.Tensor:
+    """w_prev per overlap frame, computed in bf16 like the reference (the blend runs on bf16 tensors)
+    [ref: core/generation_utils.py:284-312]."""
+    dt = torch.bfloat16
+    if overlap >= 3:
+        t = torch.linspace(0.0, 1.0, steps=overlap, dtype=dt)
+        u = ((t - 1.0 / 3.0) / (2.0 / 3.0 - 1.0 / 3.0)).clamp(0.0, 1.0)
+        w = 0.5 + 0.5 * torch.cos(torch.pi * u)
+    else:
+        w = torch.linspace(1.0, 0.0, steps=overlap, dtype=dt)
+    return w.float()
+
+
+# ----------------------------------------------------------------------------- the upscaler
+class SeedVR2Pipeline:
+    """Owns a VAE + DiT pair on one device and runs batches of LR frames through them."""
+
+    def __init__(self, vae, dit, text_pos: torch.Tensor, device):
+        self.vae, self.dit = vae, dit
+        self.device = torch.device(device)
+        self.text_pos = text_pos.to(self.device).to(torch.bfloat16).contiguous()
+        self._taps = {}
+
+    def _resize_taps(self, hin, win, rh, rw):
+        key = (hin, win, rh, rw)
+        if key not in self._taps:
+            wy, ymin, ycnt = aa_bicubic_taps(hin, rh)
+            wx, xmin, xcnt = aa_bicubic_taps(win, rw)
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            self._taps[key] = tuple(up(a) for a in (wy, ymin, ycnt, wx, xmin, xcnt))
+        return self._taps[key]
+
+    # one batch, device resident ------------------------------------------------------------
+    def transform(self, frames: torch.Tensor, resolution: int, max_resolution: int = 0) -> torch.Tensor:
+        """frames bf16 [T,Hin,Win,3] in [0,1] -> bf16 [T,Hp,Wp,3] in [-1,1] (padding = -1)."""
+        T, hin, win, _ = frames.shape
+        rh, rw, _, _, ph, pw = target_dims(hin, win, resolution, max_resolution)
+        return hip.resize_pad_normalize(frames, self._resize_taps(hin, win, rh, rw), ph, pw)
+
+    @staticmethod
+    def make_noise(latent_shape, seed: int) -> torch.Tensor:
+        """Noise is drawn by the CPU generator on a bf16 CPU tensor, exactly like the reference's CPU path:
+        torch.manual_seed(seed); randn_like(latent)  [ref: core/generation_phases.py:659,676-679;
+        common/seed.py:23-29].  (A second randn_like is drawn there for the unused aug noise.)"""
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        return torch.randn(tuple(latent_shape), generator=g, dtype=torch.bfloat16, device="cpu")
+
+    def upscale_batch(self, lr_frames: torch.Tensor, resolution: int, seed: int, max_resolution: int = 0,
+                      noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """lr_frames bf16 [T(4n+1),Hin,Win,3] on the device -> decoded bf16 [T,Hp,Wp,3] in ~[-1,1]."""
+        x = self.transform(lr_frames, resolution, max_resolution)
+        latent = self.vae.encode(x)
+        del x
+        if noise is None:
+            noise = self.make_noise(latent.shape, seed)
+        noise = noise.to(self.device).contiguous()
+        x0 = self.dit.one_step(noise, latent, self.text_pos)
+        del latent, noise
+        return self.vae.decode(x0)
+
+    # whole clip ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, frames: torch.Tensor, resolution: int, batch_size: int = 5, temporal_overlap: int = 0,
+                 seed: int = 42, max_resolution: int = 0, uniform_batch_size: bool = False,
+                 progress=None) -> torch.Tensor:
+        """frames [N,Hin,Win,3] float in [0,1] (any device) -> bf16 [N,true_h,true_w,3] in [0,1] on the device."""
+        N, hin, win, _ = frames.shape
+        rh, rw, th, tw, ph, pw = target_dims(hin, win, resolution, max_resolution)
+        batches, overlap = plan_batches(N, batch_size, temporal_overlap, uniform_batch_size)
+        src = frames.to(self.device).to(torch.bfloat16)
+        # every source frame is written exactly once  [ref: generation_phases.py:868 (pre-allocated final_video)]
+        final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16, device=self.device)
+        w_prev = blend_weights(overlap).to(self.device) if overlap else None
+        write = 0
+        for bi, b in enumerate(batches):
+            idx = torch.tensor(b.index, device=self.device)
+            dec = self.upscale_batch(src.index_select(0, idx).contiguous(), resolution, seed, max_resolution)
+            sample = hip.crop_to_unit(dec[: b.ori_len].contiguous(), th, tw, to_unit=False)  # trim temporal+spatial pad
+            del dec
+            if bi > 0 and overlap and overlap < sample.shape[0] and write >= overlap:
+                tail = final[write - overlap:write]
+                hip.blend_overlap(tail.clone(), sample[:overlap].contiguous(), w_prev, tail)
+                sample = sample[overlap:]
+            final[write:write + sample.shape[0]] = sample
+            write += sample.shape[0]
+            if progress:
+                progress(bi + 1, len(batches))
+        final = final[:write]
+        # phase 4 with color_correction='none': clamp(-1,1)*0.5+0.5  [ref: generation_phases.py:1337]
+        return hip.crop_to_unit(final, th, tw, to_unit=True)

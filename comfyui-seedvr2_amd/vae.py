@@ -1,0 +1,279 @@
+"""Causal 3-D video VAE (s8 / t4 / 16 latent channels) on the HIP kernels, channels-last (NDHWC).
+
+Mirrors ``VideoAutoencoderKLWrapper.encode/decode`` and the temporal slicing schedule of the reference
+[ref: src/models/video_vae_v3/modules/attn_video_vae.py:1246-1292 (slicing_encode/decode),
+ :808-856 (Encoder3D.forward), :983-1035 (Decoder3D.forward), :311-362 (ResnetBlock3D),
+ :110-174 (Upsample3D), :229-250 (Downsample3D), :656-668 (mid block);
+ causal_inflation_lib.py:213-305 (causal conv with carried frames)].
+
+Every stage is one launch from libseedvr2_hip:
+    conv3d (implicit GEMM, causal head from carry buffers, fused bias + residual)
+    groupnorm_silu (per-frame statistics + fused SiLU)
+    gemm (1x1x1 convs, attention projections, Upsample3D's channel expansion with fused pixel-shuffle store)
+    attn_d512 (mid-block spatial attention)
+Temporal chunks carry each conv's last (k_t - s_t) input frames exactly like the reference's
+``MemoryState.INITIALIZING / ACTIVE`` protocol, so chunking only bounds memory and never changes results.
+Weights are taken in the reference's state-dict layout ([Cout, Cin, kt, kh, kw] convs).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import hip
+
+
+@dataclass
+class VAEConfig:
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 16
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_groups: int = 32
+    temporal_scale_num: int = 2
+    eps: float = 1e-6
+    scaling_factor: float = 0.9152
+    # temporal slicing [ref: configs_3b/main.yaml:53-55; core/model_configuration.py:1237-1248]
+    encode_split: int = 4   # input frames per slice after the first (first slice = 1 + encode_split)
+    decode_split: int = 1   # latent frames per slice after the first (first slice = 1 + decode_split)
+
+
+class _State:
+    def __init__(self):
+        self.mem: Dict[str, torch.Tensor] = {}
+        self.active = False
+
+
+class VideoVAEHip:
+    def __init__(self, cfg: VAEConfig, params: Dict[str, torch.Tensor], device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        dev = self.device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.convs: Dict[str, dict] = {}
+        self.norms: Dict[str, tuple] = {}
+        self.attn: Dict[str, dict] = {}
+        for k, v in params.items():
+            if k.endswith(".weight") and v.dim() == 5:
+                name = k[: -len(".weight")]
+                cout, cin, kt, kh, kw = v.shape
+                w = v.detach().to(dev).permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw * cin)
+                ent = {"cout": cout, "cin": cin, "k": (kt, kh, kw), "bias": f32(params[name + ".bias"])}
+                if cin % 64 == 0:
+                    ent["w"] = hip.pad_weight(w)
+                else:  # small-Cin layers (3, 16): explicit im2col + GEMM
+                    ent["kpad"] = (kt * kh * kw * cin + 63) // 64 * 64
+                    ent["w"] = hip.pad_weight(w, ent["kpad"])
+                self.convs[name] = ent
+            elif k.endswith(".weight") and v.dim() == 1:
+                name = k[: -len(".weight")]
+                self.norms[name] = (f32(v), f32(params[name + ".bias"]))
+        for side in ("encoder", "decoder"):
+            a = f"{side}.mid_block.attentions.0"
+            if (a + ".to_q.weight") in params:
+                wq = torch.cat([params[f"{a}.{l}.weight"].detach().to(dev) for l in ("to_q", "to_k", "to_v")], dim=0)
+                bq = torch.cat([f32(params[f"{a}.{l}.bias"]) for l in ("to_q", "to_k", "to_v")]).contiguous()
+                self.attn[a] = {"w_qkv": hip.pad_weight(wq), "b_qkv": bq,
+                                "w_out": hip.pad_weight(params[f"{a}.to_out.0.weight"].detach().to(dev)),
+                                "b_out": f32(params[f"{a}.to_out.0.bias"]), "c": wq.shape[1]}
+
+    # ------------------------------------------------------------------ primitives
+    def _conv(self, name: str, x: torch.Tensor, st: _State, stride=(1, 1, 1), pad_hw=None,
+              resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+        c = self.convs[name]
+        kt, kh, kw = c["k"]
+        if pad_hw is None:
+            pad_hw = (kh // 2, kh // 2, kw // 2, kw // 2)
+        keep = kt - stride[0]  # frames of input carried to the next chunk
+        if st.active and keep > 0:
+            carry, npad = st.mem[name], keep
+        else:
+            carry, npad = None, 2 * ((kt - 1) // 2)  # first chunk: replicate frame 0  [ref: causal_inflation_lib.py:422-437]
+        if keep > 0:
+            if x.shape[0] >= keep:
+                new_mem = x[x.shape[0] - keep:].clone()
+            else:
+                head = carry if carry is not None else x[:1].expand(npad, -1, -1, -1)
+                new_mem = torch.cat((head, x), dim=0)[-keep:].contiguous()
+        if "kpad" in c:
+            col = hip.im2col3d(x, c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry, kpad=c["kpad"])
+            to, ho, wo = hip.conv_out_size(x.shape[0], x.shape[1], x.shape[2], c["k"], stride, npad, pad_hw)
+            y = hip.gemm(col, c["w"], c["cout"], bias=c["bias"]).view(to, ho, wo, c["cout"])
+            if resid is not None:
+                raise hip.HipError("small-Cin conv has no residual path")
+        else:
+            y = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
+                           bias=c["bias"], resid=resid)
+        if keep > 0:
+            st.mem[name] = new_mem
+        return y
+
+    def _norm(self, name: str, x: torch.Tensor, silu: bool = True) -> torch.Tensor:
+        g, b = self.norms[name]
+        return hip.groupnorm_silu(x, g, b, self.cfg.norm_groups, self.cfg.eps, silu=silu)
+
+    def _resnet(self, name: str, x: torch.Tensor, st: _State) -> torch.Tensor:
+        h = self._norm(name + ".norm1", x)
+        h = self._conv(name + ".conv1", h, st)
+        h = self._norm(name + ".norm2", h)
+        skip = x
+        if (name + ".conv_shortcut") in self.convs:
+            skip = self._conv(name + ".conv_shortcut", x, st, pad_hw=(0, 0, 0, 0))
+        return self._conv(name + ".conv2", h, st, resid=skip)
+
+    def _mid_attention(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        a = self.attn[name]
+        T, H, W, Cc = x.shape
+        if Cc != 512:
+            raise hip.HipError("mid-block attention kernel is built for 512 channels")
+        h = self._norm(name + ".group_norm", x, silu=False).view(T * H * W, Cc)
+        qkv = hip.gemm(h, a["w_qkv"], 3 * Cc, bias=a["b_qkv"])
+        o = hip.attn_d512(qkv, T, H * W)
+        out = hip.gemm(o, a["w_out"], Cc, bias=a["b_out"], resid=x.view(T * H * W, Cc))
+        return out.view(T, H, W, Cc)
+
+    def _mid(self, side: str, x: torch.Tensor, st: _State) -> torch.Tensor:
+        x = self._resnet(f"{side}.mid_block.resnets.0", x, st)
+        x = self._mid_attention(f"{side}.mid_block.attentions.0", x)
+        return self._resnet(f"{side}.mid_block.resnets.1", x, st)
+
+    def _upsample(self, name: str, x: torch.Tensor, tz: int, st: _State) -> torch.Tensor:
+        c = self.convs[name + ".upscale_conv"]
+        T, H, W, Cc = x.shape
+        drop = tz == 2 and not st.active  # remove_head on the first chunk  [ref: attn_video_vae.py:152-153]
+        y = hip.gemm(x.view(T * H * W, Cc), c["w"], c["cout"], epilogue=hip.EPI_PIXSHUF3D, bias=c["bias"],
+                     pixshuf=(T, H, W, Cc, tz, drop))
+        return self._conv(name + ".conv", y, st)
+
+    # ------------------------------------------------------------------ encoder / decoder on one chunk
+    def _encoder(self, x: torch.Tensor, st: _State) -> torch.Tensor:
+        cfg = self.cfg
+        n = len(cfg.block_out_channels)
+        h = self._conv("encoder.conv_in", x, st)
+        for i in range(n):
+            for j in range(cfg.layers_per_block):
+                h = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", h, st)
+            if i != n - 1:
+                tdown = i >= n - cfg.temporal_scale_num - 1
+                h = self._conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", h, st,
+                               stride=(2 if tdown else 1, 2, 2), pad_hw=(0, 1, 0, 1))
+        h = self._mid("encoder", h, st)
+        h = self._norm("encoder.conv_norm_out", h)
+        return self._conv("encoder.conv_out", h, st)
+
+    def _decoder(self, z: torch.Tensor, st: _State) -> torch.Tensor:
+        cfg = self.cfg
+        n = len(cfg.block_out_channels)
+        h = self._conv("decoder.conv_in", z, st)
+        h = self._mid("decoder", h, st)
+        for i in range(n):
+            for j in range(cfg.layers_per_block + 1):
+                h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", h, st)
+            if i != n - 1:
+                h = self._upsample(f"decoder.up_blocks.{i}.upsamplers.0", h, 2 if i < cfg.temporal_scale_num else 1, st)
+        h = self._norm("decoder.conv_norm_out", h)
+        return self._conv("decoder.conv_out", h, st)
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x bf16 [T,H,W,3] in [-1,1], T = 4n+1, H,W multiples of 8 -> latent bf16 [T_l,h,w,16]
+        (posterior mean * scaling_factor)  [ref: src/core/infer.py:117-188; attn_video_vae.py:1672-1681]."""
+        cfg = self.cfg
+        T = x.shape[0]
+        if x.dim() != 4 or x.shape[3] != cfg.in_channels or T % 4 != 1 or x.shape[1] % 8 or x.shape[2] % 8:
+            raise hip.HipError(f"encode: expected [4n+1, 8a, 8b, {cfg.in_channels}], got {tuple(x.shape)}")
+        st = _State()
+        split = cfg.encode_split
+        outs = []
+        a = 0
+        while a < T:
+            b = min(T, a + (1 + split if a == 0 else split)) if (T - 1) > split else T
+            outs.append(self._encoder(x[a:b].contiguous(), st)[..., : cfg.latent_channels])
+            st.active = True
+            a = b
+        m = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        return (m.float() * cfg.scaling_factor).to(torch.bfloat16).contiguous()
+
+    @torch.no_grad()
+    def decode(self, latent: torch.Tensor) -> torch.Tensor:
+        """latent bf16 [T_l,h,w,16] -> bf16 [T,H,W,3], T = 4(T_l-1)+1  [ref: src/core/infer.py:192-257]."""
+        cfg = self.cfg
+        if latent.dim() != 4 or latent.shape[3] != cfg.latent_channels:
+            raise hip.HipError(f"decode: expected [T_l,h,w,{cfg.latent_channels}], got {tuple(latent.shape)}")
+        z = (latent.float() / cfg.scaling_factor).to(torch.bfloat16).contiguous()
+        Tl = z.shape[0]
+        st = _State()
+        split = cfg.decode_split
+        outs = []
+        a = 0
+        while a < Tl:
+            b = min(Tl, a + (1 + split if a == 0 else split)) if (Tl - 1) > split else Tl
+            outs.append(self._decoder(z[a:b].contiguous(), st))
+            st.active = True
+            a = b
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+
+def synthetic_state_dict(cfg: VAEConfig, device, seed: int = 0, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Random-init VAE weights in the reference's key layout, generated on `device` (bench only)."""
+    import math
+    g = torch.Generator(device=device).manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    ch = cfg.block_out_channels
+    n = len(ch)
+
+    def conv(name, cin, cout, k):
+        fan = cin * k[0] * k[1] * k[2]
+        out[name + ".weight"] = (torch.randn(cout, cin, *k, generator=g, device=device) / math.sqrt(fan)).to(dtype)
+        out[name + ".bias"] = (0.05 * torch.randn(cout, generator=g, device=device)).to(dtype)
+
+    def norm(name, c):
+        out[name + ".weight"] = (1 + 0.1 * torch.randn(c, generator=g, device=device)).to(dtype)
+        out[name + ".bias"] = (0.05 * torch.randn(c, generator=g, device=device)).to(dtype)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cin, cout, (3, 3, 3))
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, (3, 3, 3))
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, (1, 1, 1))
+
+    def mid(name, c):
+        resnet(name + ".resnets.0", c, c)
+        norm(name + ".attentions.0.group_norm", c)
+        for l in ("to_q", "to_k", "to_v", "to_out.0"):
+            out[f"{name}.attentions.0.{l}.weight"] = (torch.randn(c, c, generator=g, device=device) / math.sqrt(c)).to(dtype)
+            out[f"{name}.attentions.0.{l}.bias"] = (0.05 * torch.randn(c, generator=g, device=device)).to(dtype)
+        resnet(name + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", cfg.in_channels, ch[0], (3, 3, 3))
+    cout = ch[0]
+    for i in range(n):
+        cin, cout = cout, ch[i]
+        for j in range(cfg.layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != n - 1:
+            tdown = i >= n - cfg.temporal_scale_num - 1
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, (3 if tdown else 1, 3, 3))
+    mid("encoder.mid_block", ch[-1])
+    norm("encoder.conv_norm_out", ch[-1])
+    conv("encoder.conv_out", ch[-1], 2 * cfg.latent_channels, (3, 3, 3))
+    rev = list(reversed(ch))
+    conv("decoder.conv_in", cfg.latent_channels, rev[0], (3, 3, 3))
+    mid("decoder.mid_block", rev[0])
+    cout = rev[0]
+    for i in range(n):
+        cin, cout = cout, rev[i]
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != n - 1:
+            tz = 2 if i < cfg.temporal_scale_num else 1
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.upscale_conv", cout, cout * 4 * tz, (1, 1, 1))
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, (3, 3, 3))
+    norm("decoder.conv_norm_out", ch[0])
+    conv("decoder.conv_out", ch[0], cfg.out_channels, (3, 3, 3))
+    return out

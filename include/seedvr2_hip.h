@@ -180,6 +180,47 @@ int svr2_patch_in(const void* noise, const void* latent, void* rows, int32_t T, 
 int svr2_patch_out_x0(const void* pred, int64_t ldp, const void* noise, void* x0, int32_t T, int32_t H,
                       int32_t W, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------ VAE: per-frame GroupNorm (+SiLU)
+ * GroupNorm over (H*W, C/G) of every frame, channels-last x [F, P, C] (P = H*W pixels)
+ *   [ref: models/video_vae_v3/modules/causal_inflation_lib.py:354-409 (causal_norm_wrapper:
+ *    'b c t h w -> (b t) c h w' then F.group_norm, eps 1e-6), attn_video_vae.py:316-318,344,350]
+ * svr2_groupnorm_stats: two launches (fp32 partial sums per strip, fp64 fold) -> coef [F, C, 2] with
+ *   y = x * coef[..,0] + coef[..,1];  workspace: svr2_groupnorm_ws_floats(F, P, C) floats.
+ * svr2_groupnorm_apply: y = x*a + b, optionally followed by SiLU (the nonlinearity that follows
+ *   every norm in ResnetBlock3D / conv_norm_out). */
+int64_t svr2_groupnorm_ws_floats(int32_t F, int64_t P, int32_t C);
+int svr2_groupnorm_stats(const void* x, int32_t F, int64_t P, int32_t C, int32_t G, float eps,
+                         const float* gamma, const float* beta, float* workspace, float* coef, void* stream);
+int svr2_groupnorm_apply(const void* x, const float* coef, void* y, int32_t F, int64_t P, int32_t C,
+                         int32_t silu, void* stream);
+
+/* ------------------------------------------------------------------ VAE: mid-block spatial attention
+ * Single-head attention with head dim 512 over the P = h*w tokens of every latent frame
+ *   [ref: attn_video_vae.py:615-631,661-665 (diffusers Attention, heads=1, dim_head=512, SDPA)].
+ *   q,k,v: bf16 rows of 512 with row stride ld (elements; a fused [S,1536] qkv buffer works),
+ *   frame f owns rows [f*P, (f+1)*P);  out bf16 [frames*P, ldo]. */
+int svr2_attn_d512(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo,
+                   int32_t frames, int32_t P, float scale, void* stream);
+
+/* ------------------------------------------------------------------ pixel-space stages
+ * Antialiased bicubic resize (separable taps computed by the host exactly as ATen's
+ * _upsample_bicubic2d_aa does), clamp to [0,1], zero-pad bottom/right to (Hp, Wp), (x-0.5)/0.5
+ *   [ref: core/generation_utils.py:47-84; data/image/transforms/side_resize.py:36-75,
+ *         divisible_crop.py:43-80].  in bf16 [T,Hin,Win,3] -> out bf16 [T,Hp,Wp,3] (channels-last).
+ *   wy [Hout,KY], ymin/ycnt [Hout]; wx [Wout,KX], xmin/xcnt [Wout]. */
+int svr2_resize_pad_normalize(const void* in, void* out, const float* wy, const int32_t* ymin,
+                              const int32_t* ycnt, const float* wx, const int32_t* xmin, const int32_t* xcnt,
+                              int32_t T, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t Hp,
+                              int32_t Wp, int32_t KY, int32_t KX, void* stream);
+/* out = prev_tail * w_prev[t] + cur_head * (1 - w_prev[t]) per frame t of the temporal overlap
+ *   [ref: core/generation_utils.py:284-312; generation_phases.py:968-986]. */
+int svr2_blend_overlap(const void* prev_tail, const void* cur_head, void* out, const float* w_prev,
+                       int64_t frame_elems, int32_t overlap, void* stream);
+/* Crop [T,Hp,Wp,3] -> [T,H,W,3]; to_unit != 0 also applies clamp(-1,1)*0.5+0.5
+ *   [ref: core/generation_phases.py:942-958, 1337]. */
+int svr2_crop_to_unit(const void* in, void* out, int32_t T, int32_t Hp, int32_t Wp, int32_t H, int32_t W,
+                      int32_t to_unit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

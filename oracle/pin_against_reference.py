@@ -257,6 +257,53 @@ def main():
     check("G9 one-step endpoint x0 = x - f(x)", x - (0.3 * x + 1.0), res, 1e-6)
     meta["G9"] = {"t_seen": float(seen["t"])}
 
+    # ------------------------------------------------------------------ G10 causal conv / norm of the VAE
+    from seedvr2_ref import vae as ovae
+    from src.models.video_vae_v3.modules import causal_inflation_lib as cil
+    from src.models.video_vae_v3.modules.types import MemoryState
+    vt = {}
+    for tag, k, s, pad in (("k3s1", 3, 1, 1), ("k3s2", 3, 2, 1), ("k133", (1, 3, 3), (1, 2, 2), (0, 0, 0)),
+                           ("k1", 1, 1, 0)):
+        torch.manual_seed(11)
+        conv = cil.init_causal_conv3d(8, 12, k, stride=s, padding=pad, inflation_mode="pad")
+        conv.eval()
+        x = torch.randn(1, 8, 9, 10, 12)
+        name = "c"
+        pp = {"c.weight": conv.weight.detach(), "c.bias": conv.bias.detach()}
+        sp = (0, 0, 0, 0) if tag in ("k133", "k1") else (1, 1, 1, 1)
+        st3 = (s, s, s) if isinstance(s, int) else s
+        with torch.no_grad():
+            full = conv(x, memory_state=MemoryState.DISABLED)
+            mine = ovae.causal_conv(pp, name, x[0], stride=st3, pad_hw=sp)
+            check(f"G10 causal conv {tag} unsliced", mine, full[0], 1e-5)
+            for limit in (float("inf"), 1e-5):   # 1e-5 GiB forces the recursive H/W splitting path
+                conv.set_memory_limit(limit)
+                outs = [conv(x[:, :, :5].clone(), memory_state=MemoryState.INITIALIZING)]
+                for a in (5, 7):
+                    outs.append(conv(x[:, :, a:a + 2].clone(), memory_state=MemoryState.ACTIVE))
+                sliced = torch.cat(outs, dim=2)
+                conv.memory = None
+                check(f"G10 reference sliced == unsliced {tag} limit={limit}", sliced, full, 1e-5)
+            sto = ovae.State()
+            mo = [ovae.causal_conv(pp, name, x[0, :, :5], stride=st3, pad_hw=sp, st=sto)]
+            sto.active = True
+            for a in (5, 7):
+                mo.append(ovae.causal_conv(pp, name, x[0, :, a:a + 2], stride=st3, pad_hw=sp, st=sto))
+            check(f"G10 oracle sliced == reference {tag}", torch.cat(mo, dim=1), full[0], 1e-5)
+        vt.update({f"G10.{tag}.x": x[0], f"G10.{tag}.w": pp["c.weight"], f"G10.{tag}.b": pp["c.bias"],
+                   f"G10.{tag}.y": full[0]})
+    gn = torch.nn.GroupNorm(4, 8, eps=1e-6)
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.1 * torch.randn(8)); gn.bias.copy_(0.1 * torch.randn(8))
+        xg = torch.randn(1, 8, 3, 6, 5)
+        ref = cil.causal_norm_wrapper(gn, xg)
+        mine = ovae.group_norm_per_frame({"n.weight": gn.weight, "n.bias": gn.bias}, "n", xg[0], 4, 1e-6)
+        check("G10 causal_norm_wrapper (per-frame GroupNorm)", mine, ref[0], 1e-6)
+        xh = torch.randn(1, 2, 6, 3, 3)
+        check("G10 remove_head", torch.cat((xh[0][:, :1], xh[0][:, 2:]), dim=1), cil.remove_head(xh)[0])
+    vt.update({"G10.gn.x": xg[0], "G10.gn.w": gn.weight.detach(), "G10.gn.b": gn.bias.detach(), "G10.gn.y": ref[0]})
+    save_file({k: v.contiguous() for k, v in vt.items()}, os.path.join(GOLD, "vae_pins.safetensors"))
+
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
     with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:
         json.dump(meta, fh)

@@ -17,4 +17,4 @@ Parity status (see DESIGN.md "Oracle"):
     torchvision resize): restated from the libraries' published algorithms.
 """
 
-from . import windows, rope, dit  # noqa: F401
+from . import windows, rope, dit, vae, pipeline  # noqa: F401

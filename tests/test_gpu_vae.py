@@ -1,0 +1,122 @@
+"""GPU parity tests of the VAE kernels, the VAE runner and the whole pipeline vs the CPU oracle
+(through the C ABI).  Floating point: tolerances are stated per test; the end-to-end bar is PSNR on
+decoded RGB between the HIP path and the fp32 oracle, with the bf16 oracle's own PSNR as the yardstick."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests_support import assert_close, bf, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+def dev_bf16(x, gpu):
+    return x.to(gpu).to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("Fr,H,W,C,silu", [(3, 9, 13, 128, True), (2, 40, 56, 512, True), (1, 17, 5, 64, False),
+                                           (5, 64, 48, 256, True)])
+def test_groupnorm_silu(pkg, gpu, Fr, H, W, C, silu):
+    x = rnd(Fr, H, W, C, seed=1, scale=2.0) + 0.7
+    g, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    out = pkg.hip.groupnorm_silu(dev_bf16(x, gpu), g.to(gpu), b.to(gpu), 32, 1e-6, silu=silu)
+    ref = F.group_norm(x.permute(0, 3, 1, 2), 32, g, b, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    assert_close(out, ref.permute(0, 2, 3, 1), "groupnorm_silu")
+
+
+@pytest.mark.parametrize("frames,P", [(2, 200), (1, 4096), (3, 129)])
+def test_attn_d512(pkg, gpu, frames, P):
+    qkv = rnd(frames * P, 1536, seed=4)
+    out = pkg.hip.attn_d512(dev_bf16(qkv, gpu), frames, P).float().cpu()
+    q, k, v = (qkv[:, i * 512:(i + 1) * 512].reshape(frames, P, 512) for i in range(3))
+    ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(512), dim=-1) @ v
+    assert_close(out.reshape(frames, P, 512), ref, "attn_d512", rtol=2e-2, atol_rel=2e-2)
+
+
+def test_resize_pad_normalize(pkg, gpu):
+    from seedvr2_ref import pipeline as opipe
+    P = pkg.pipeline
+    frames = bf(torch.rand(3, 27, 40, 3, generator=torch.Generator().manual_seed(5)))
+    pipe = P.SeedVR2Pipeline(None, None, torch.zeros(1, 8), gpu)
+    got = pipe.transform(dev_bf16(frames, gpu), 54).float().cpu()
+    ref = opipe.transform(frames.to(torch.bfloat16).permute(0, 3, 1, 2), 54).float().permute(1, 2, 3, 0)
+    assert got.shape == ref.shape == (3, 64, 80, 3)
+    # identical rounding points; the only freedom is fp32 summation order inside the resize (<= 1 bf16 ulp)
+    assert (got - ref).abs().max() <= 2 ** -7
+    assert ((got - ref).abs() > 0).float().mean() < 0.02
+
+
+def _vae_pair(pkg, gpu, seed=0):
+    from seedvr2_ref import vae as ovae
+    ch = (64, 128, 512, 512)
+    ocfg = ovae.VAEConfig(block_out_channels=ch)
+    p = {k: bf(v) for k, v in ovae.synthetic_params(ocfg, seed).items()}
+    model = pkg.vae.VideoVAEHip(pkg.vae.VAEConfig(block_out_channels=ch), p, gpu)
+    return ovae, ocfg, p, model
+
+
+def _rel(a, b):
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def test_vae_encode_vs_oracle(pkg, gpu):
+    ovae, ocfg, p, model = _vae_pair(pkg, gpu)
+    x = bf(torch.rand(9, 32, 48, 3, generator=torch.Generator().manual_seed(6)) * 2 - 1)
+    got = model.encode(dev_bf16(x, gpu)).float().cpu()
+    ref32 = ovae.encode(p, x.permute(3, 0, 1, 2), ocfg, torch.float32)
+    ref16 = ovae.encode(p, x.permute(3, 0, 1, 2), ocfg, torch.bfloat16).float()
+    e_hip, e_b16 = _rel(got, ref32), _rel(ref16, ref32)
+    print(f"VAE encode: rel-rms err hip={e_hip:.3e} bf16-oracle={e_b16:.3e}")
+    assert got.shape == ref32.shape == (3, 4, 6, 16)
+    assert e_hip <= 2.0 * e_b16 + 2e-3
+
+
+def test_vae_decode_vs_oracle_and_chunking(pkg, gpu):
+    ovae, ocfg, p, model = _vae_pair(pkg, gpu)
+    z = bf(torch.randn(3, 4, 6, 16, generator=torch.Generator().manual_seed(7)))
+    got = model.decode(dev_bf16(z, gpu)).float().cpu()
+    ref32 = ovae.decode(p, z, ocfg, torch.float32).permute(1, 2, 3, 0)
+    ref16 = ovae.decode(p, z, ocfg, torch.bfloat16).float().permute(1, 2, 3, 0)
+    e_hip, e_b16 = _rel(got, ref32), _rel(ref16, ref32)
+    print(f"VAE decode: rel-rms err hip={e_hip:.3e} bf16-oracle={e_b16:.3e}")
+    assert got.shape == ref32.shape == (9, 32, 48, 3)
+    assert e_hip <= 2.0 * e_b16 + 2e-3
+    # chunk schedule is only a memory schedule: a different split gives (nearly) the same pixels
+    model.cfg.decode_split = 8
+    whole = model.decode(dev_bf16(z, gpu)).float().cpu()
+    model.cfg.decode_split = 1
+    assert _rel(whole, got) < 5e-3
+
+
+def test_pipeline_end_to_end_psnr(pkg, gpu):
+    """LR clip -> upscaled clip, two overlapping batches: HIP path vs fp32 oracle on decoded RGB in [0,1]."""
+    from seedvr2_ref import dit as odit, pipeline as opipe
+    ovae, ocfg, vp, vae = _vae_pair(pkg, gpu, seed=1)
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=2, mm_layers=1, txt_in_dim=64, mlp_multiple_of=64)
+    dcfg = odit.DiTConfig(**kw)
+    dp = {k: bf(v) for k, v in odit.synthetic_params(dcfg, 2).items()}
+    dit = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(**kw), dp, gpu)
+    txt = bf(torch.randn(58, 64, generator=torch.Generator().manual_seed(8)))
+    lr = torch.rand(7, 4, 6, 3, generator=torch.Generator().manual_seed(9))
+    lr = F.interpolate(lr.permute(0, 3, 1, 2), size=(16, 24), mode="bicubic").permute(0, 2, 3, 1).clamp(0, 1)
+    lr = (lr * 255).round() / 255  # uint8-quantised like the CLI input
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    got = pipe.generate(lr, resolution=32, batch_size=5, temporal_overlap=2, seed=42).float().cpu()
+    ref32 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.float32).float()
+    ref16 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.bfloat16).float()
+    assert got.shape == ref32.shape == (7, 32, 48, 3)
+    p_hip, p_b16 = psnr(got, ref32), psnr(ref16, ref32)
+    print(f"end-to-end PSNR vs fp32 oracle: hip={p_hip:.2f} dB, bf16 oracle={p_b16:.2f} dB, "
+          f"max|d|={float((got - ref32).abs().max()):.4f}")
+    assert p_hip >= p_b16 - 3.0 and p_hip > 30.0
