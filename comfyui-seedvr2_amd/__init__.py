@@ -14,3 +14,8 @@ from . import windows  # noqa: F401
 from . import dit  # noqa: F401
 from . import vae  # noqa: F401
 from . import pipeline  # noqa: F401
+from . import parallel  # noqa: F401
+from . import weights  # noqa: F401
+from . import infer  # noqa: F401
+from . import nodes  # noqa: F401
+from .nodes import comfy_entrypoint, SeedVR2Extension  # noqa: F401  (ComfyUI V3 entry point)

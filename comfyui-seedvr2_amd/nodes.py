@@ -1,0 +1,122 @@
+"""The four ComfyUI V3 nodes of the reference, same ids / inputs / outputs, backed by the HIP pipeline
+[ref: src/interfaces/video_upscaler.py:37-571, dit_model_loader.py, vae_model_loader.py,
+ torch_compile_settings.py, interfaces/__init__.py:14-29].  ComfyUI's ``comfy_api`` is not installed in
+the build image, so the classes also work standalone (``execute`` is a plain classmethod)."""
+
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from . import dit as _dit
+from . import pipeline as _pipeline
+from . import vae as _vae
+from . import weights as _weights
+
+try:  # pragma: no cover - only inside ComfyUI
+    from comfy_api.latest import ComfyExtension, io  # type: ignore
+    _Base = io.ComfyNode
+except Exception:  # standalone
+    io = None
+    ComfyExtension = object
+    _Base = object
+
+UPSCALER_INPUTS = ["image", "dit", "vae", "seed", "resolution", "max_resolution", "batch_size", "uniform_batch_size",
+                   "temporal_overlap", "prepend_frames", "color_correction", "input_noise_scale",
+                   "latent_noise_scale", "offload_device", "enable_debug"]
+DIT_KEYS = ["model", "device", "offload_device", "cache_model", "blocks_to_swap", "swap_io_components",
+            "attention_mode", "torch_compile_args", "node_id"]
+VAE_KEYS = ["model", "device", "offload_device", "cache_model", "encode_tiled", "encode_tile_size",
+            "encode_tile_overlap", "decode_tiled", "decode_tile_size", "decode_tile_overlap", "tile_debug",
+            "torch_compile_args", "node_id"]
+
+_PIPELINES: Dict[Any, _pipeline.SeedVR2Pipeline] = {}
+
+
+def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pipeline.SeedVR2Pipeline:
+    key = (dit_cfg["model"], vae_cfg["model"], dit_cfg["device"])
+    if key not in _PIPELINES:
+        dev = torch.device(dit_cfg["device"])
+        dpath = _weights.find_model_file(dit_cfg["model"])
+        vpath = _weights.find_model_file(vae_cfg["model"])
+        if dpath is None or vpath is None:
+            raise RuntimeError(f"model files not found: {dit_cfg['model']} / {vae_cfg['model']} "
+                               "(no network download on this path; place them under models/SEEDVR2)")
+        if _weights.config_for(dit_cfg["model"]) != "3b":
+            raise NotImplementedError("NaDiT-7B deltas are not wired into the HIP runner yet")
+        dit = _dit.NaDiTHip(_dit.CFG_3B, _weights.load_state_dict(dpath), dev)
+        vae = _vae.VideoVAEHip(_vae.VAEConfig(), _weights.load_state_dict(vpath), dev)
+        _PIPELINES[key] = _pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev)
+    return _PIPELINES[key]
+
+
+class SeedVR2LoadDiTModel(_Base):
+    @classmethod
+    def execute(cls, model: str = _weights.DEFAULT_DIT, device: str = "cuda:0", offload_device: str = "none",
+                cache_model: bool = False, blocks_to_swap: int = 0, swap_io_components: bool = False,
+                attention_mode: str = "sdpa", torch_compile_args=None, node_id=None):
+        if blocks_to_swap:
+            raise ValueError("BlockSwap is not needed on 288 GB HBM; set blocks_to_swap=0")
+        cfg = dict(zip(DIT_KEYS, (model, device, offload_device, cache_model, 0, False, attention_mode,
+                                  torch_compile_args, node_id)))
+        return (cfg,)
+
+
+class SeedVR2LoadVAEModel(_Base):
+    @classmethod
+    def execute(cls, model: str = _weights.DEFAULT_VAE, device: str = "cuda:0", offload_device: str = "none",
+                cache_model: bool = False, encode_tiled: bool = False, encode_tile_size: int = 1024,
+                encode_tile_overlap: int = 128, decode_tiled: bool = False, decode_tile_size: int = 1024,
+                decode_tile_overlap: int = 128, tile_debug: str = "false", torch_compile_args=None, node_id=None):
+        if encode_tiled or decode_tiled:
+            raise NotImplementedError("VAE tiling is not implemented on the MI355X path (untiled fits in HBM)")
+        cfg = dict(zip(VAE_KEYS, (model, device, offload_device, cache_model, False, encode_tile_size,
+                                  encode_tile_overlap, False, decode_tile_size, decode_tile_overlap, tile_debug,
+                                  torch_compile_args, node_id)))
+        return (cfg,)
+
+
+class SeedVR2TorchCompileSettings(_Base):
+    @classmethod
+    def execute(cls, **kwargs):
+        return (dict(kwargs),)  # accepted for graph compatibility; there is no tracing compiler on this path
+
+
+class SeedVR2VideoUpscaler(_Base):
+    @classmethod
+    def execute(cls, image: torch.Tensor, dit: dict, vae: dict, seed: int = 42, resolution: int = 1080,
+                max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
+                temporal_overlap: int = 0, prepend_frames: int = 0, color_correction: str = "lab",
+                input_noise_scale: float = 0.0, latent_noise_scale: float = 0.0, offload_device: str = "cpu",
+                enable_debug: bool = False, text_pos: torch.Tensor | None = None, pipeline=None):
+        """image [N,H,W,C] float in [0,1], C in {3,4} -> float32 CPU [N',H',W',C]
+        [ref: src/interfaces/video_upscaler.py:225-571]."""
+        if image.dim() != 4 or image.shape[-1] not in (3, 4):
+            raise ValueError("image must be [N,H,W,3|4]")
+        if image.shape[-1] == 4:
+            raise NotImplementedError("RGBA alpha upscaling is out of scope (SURVEY 8f next-4)")
+        if color_correction != "none":
+            raise NotImplementedError("colour correction runs after the hot path (SURVEY 8f next-2); use 'none'")
+        if input_noise_scale or latent_noise_scale:
+            raise NotImplementedError("noise injection scales other than 0 are not implemented")
+        if batch_size % 4 != 1:
+            raise ValueError("batch_size must follow 4n+1")
+        pipe = pipeline or _build_pipeline(dit, vae, text_pos)
+        frames = image
+        if prepend_frames > 0:  # reversed head frames, removed from the output [ref: generation_utils.py:593-652]
+            n = min(prepend_frames, max(image.shape[0] - 1, 0))
+            frames = torch.cat((image[1:n + 1].flip(0), image), dim=0) if n > 0 else image
+        out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size)
+        if prepend_frames > 0 and frames.shape[0] != image.shape[0]:
+            out = out[frames.shape[0] - image.shape[0]:]
+        return (out.float().cpu(),)
+
+
+class SeedVR2Extension(ComfyExtension):  # pragma: no cover
+    async def get_node_list(self):
+        return [SeedVR2LoadDiTModel, SeedVR2LoadVAEModel, SeedVR2TorchCompileSettings, SeedVR2VideoUpscaler]
+
+
+async def comfy_entrypoint():  # pragma: no cover
+    return SeedVR2Extension()

@@ -1,0 +1,127 @@
+"""Frame-chunk sharding across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The path shards along the frame axis only: every rank runs the whole encode -> DiT -> decode pipeline on
+its own contiguous segment; the single exchange is the `temporal_overlap` boundary: rank r+1 sends its
+first `overlap` finished frames to rank r (one point-to-point message on the direct xGMI link), rank r
+cross-fades them into its tail and rank r+1 drops them - the device-side equivalent of the reference's
+multi-GPU mode, which ships every worker's whole output through host shared memory and blends on the CPU
+[ref: inference_cli.py:1048-1209 (_gpu_processing): segment split :1082-1097 / :1118-1133,
+ boundary blend :1163-1198, blend function src/core/generation_utils.py:284-312].
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def segment_ranges(total: int, world: int, overlap: int, batch_size: int = 1, streaming: bool = True,
+                   start: int = 0) -> List[Tuple[int, int]]:
+    """[start, end) of every rank's segment, overlap frames included for all but the last rank.
+    streaming=True: base = total // world, first total % world ranks get one extra, +overlap
+    [ref: inference_cli.py:1082-1097]; streaming=False: the pre-loaded-frames split, chunk rounded up to a
+    multiple of batch_size [ref: inference_cli.py:1118-1133]."""
+    if world <= 1:
+        return [(start, start + total)]
+    out = []
+    if streaming:
+        base, rem = divmod(total, world)
+        cur = start
+        for r in range(world):
+            n = base + (1 if r < rem else 0)
+            end = cur + n
+            if r < world - 1 and overlap > 0:
+                end = min(end + overlap, start + total)
+            out.append((cur, end))
+            cur += n
+        return out
+    if overlap > 0:
+        with_ov = total // world + overlap
+        if batch_size > 1:
+            with_ov = ((with_ov + batch_size - 1) // batch_size) * batch_size
+        base = with_ov - overlap
+        for r in range(world):
+            s = r * base
+            e = total if r == world - 1 else min(s + with_ov, total)
+            out.append((start + s, start + e))
+        return out
+    sizes = [len(c) for c in torch.arange(total).chunk(world)]  # torch.chunk semantics (may yield fewer chunks)
+    cur = start
+    for n in sizes:
+        out.append((cur, cur + n))
+        cur += n
+    return out + [(cur, cur)] * (world - len(sizes))
+
+
+def blend_weights_f32(overlap: int, device=None) -> torch.Tensor:
+    """w_prev of blend_overlapping_frames in fp32 (segment boundaries are blended on fp32 [0,1] frames,
+    [ref: inference_cli.py:1167-1188])."""
+    if overlap >= 3:
+        t = torch.linspace(0.0, 1.0, steps=overlap, dtype=torch.float32, device=device)
+        u = ((t - 1.0 / 3.0) / (2.0 / 3.0 - 1.0 / 3.0)).clamp(0.0, 1.0)
+        return 0.5 + 0.5 * torch.cos(torch.pi * u)
+    return torch.linspace(1.0, 0.0, steps=overlap, dtype=torch.float32, device=device)
+
+
+def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int, dist=None) -> torch.Tensor:
+    """frames: this rank's finished frames [T,H,W,C] (any float dtype, on the rank's device).
+    Returns the frames this rank owns after the boundary exchange: tail blended with the right neighbour's
+    head, own head (already blended by the left neighbour) dropped.  No collective besides the
+    neighbour send/recv; ranks with too few frames follow the reference's edge cases."""
+    if world <= 1 or overlap <= 0:
+        return frames
+    if dist is None:
+        import torch.distributed as dist
+    T = frames.shape[0]
+    # frame counts of the neighbours decide whether a boundary is blended (reference: chunk.shape[0] > overlap)
+    counts = torch.zeros(world, dtype=torch.int64, device=frames.device)
+    counts[rank] = T
+    dist.all_reduce(counts)  # tiny control message (8 bytes per rank)
+    counts = counts.tolist()
+    reqs = []
+    recv = None
+    send_ok = rank > 0 and T > overlap and counts[rank - 1] >= overlap
+    recv_ok = rank < world - 1 and counts[rank + 1] > overlap and T >= overlap
+    if send_ok:
+        reqs.append(dist.isend(frames[:overlap].contiguous(), rank - 1))
+    if recv_ok:
+        recv = torch.empty_like(frames[:overlap])
+        reqs.append(dist.irecv(recv, rank + 1))
+    for r in reqs:
+        r.wait()
+    out = frames
+    if recv_ok:
+        w = blend_weights_f32(overlap, frames.device).view(overlap, *([1] * (frames.dim() - 1)))
+        tail = out[-overlap:].float() * w + recv.float() * (1.0 - w)
+        out = torch.cat((out[:-overlap], tail.to(out.dtype)), dim=0)
+    if rank > 0:
+        # reference: later chunks contribute chunk[overlap:] (nothing at all when chunk.shape[0] <= overlap)
+        out = out[overlap:] if T > overlap else out[:0]
+    return out
+
+
+def gather_frames(frames: torch.Tensor, rank: int, world: int, dst: int = 0, dist=None) -> Optional[torch.Tensor]:
+    """Optional second step: collect every rank's owned frames on the writer rank (point-to-point)."""
+    if world <= 1:
+        return frames
+    if dist is None:
+        import torch.distributed as dist
+    counts = torch.zeros(world, dtype=torch.int64, device=frames.device)
+    counts[rank] = frames.shape[0]
+    dist.all_reduce(counts)
+    counts = counts.tolist()
+    if rank != dst:
+        if frames.shape[0] > 0:
+            dist.send(frames.contiguous(), dst)
+        return None
+    parts = []
+    for r in range(world):
+        if r == dst:
+            parts.append(frames)
+        elif counts[r] > 0:
+            buf = torch.empty((counts[r],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+            dist.recv(buf, r)
+            parts.append(buf)
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,87 @@
+"""world_size-2 (and 3) gloo runs of the frame-chunk sharding on the CPU: partition + neighbour exchange +
+blend must equal the reference's multi-GPU semantics (segment-wise processing, boundary blend on the
+final frames), restated here from inference_cli.py:1082-1097 and :1163-1198."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _fake_upscale(seg: torch.Tensor, rank: int) -> torch.Tensor:
+    """Deterministic stand-in for the per-segment pipeline: depends on the frame id and on the segment."""
+    return (seg.float() * 0.01 + 0.1 * rank).view(-1, 1, 1, 1).expand(-1, 2, 3, 3).contiguous()
+
+
+def _reference_concat(results, overlap):
+    """The reference's parent-process concatenation [ref: inference_cli.py:1163-1198]."""
+    from seedvr2_ref.pipeline import blend_overlapping_frames
+    if overlap <= 0:
+        return torch.cat([c.float() for c in results], dim=0)
+    out = None
+    for idx, chunk in enumerate(results):
+        chunk = chunk.float()
+        if idx == 0:
+            out = chunk
+        elif chunk.shape[0] > overlap and out.shape[0] >= overlap:
+            blended = blend_overlapping_frames(out[-overlap:], chunk[:overlap], overlap)
+            out = torch.cat([out[:-overlap], blended, chunk[overlap:]], dim=0)
+        elif chunk.shape[0] > overlap:
+            out = torch.cat([out, chunk[overlap:]], dim=0)
+    return out
+
+
+def _worker(rank, world, port, total, overlap, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, e = pkg.parallel.segment_ranges(total, world, overlap)[rank]
+        mine = _fake_upscale(torch.arange(s, e), rank)
+        owned = pkg.parallel.exchange_and_blend(mine, overlap, rank, world, dist)
+        full = pkg.parallel.gather_frames(owned, rank, world, 0, dist)
+        if rank == 0:
+            q.put(full)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,total,overlap", [(2, 23, 4), (2, 10, 0), (3, 17, 2), (2, 9, 3)])
+def test_frame_sharding_matches_reference_semantics(pkg, world, total, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranges = pkg.parallel.segment_ranges(total, world, overlap)
+    ref = _reference_concat([_fake_upscale(torch.arange(s, e), r) for r, (s, e) in enumerate(ranges)], overlap)
+    assert got.shape == ref.shape and got.shape[0] == total
+    assert torch.allclose(got.float(), ref, atol=1e-6)
+
+
+def test_segment_ranges_reference_split(pkg):
+    P = pkg.parallel
+    # streaming split: base + remainder, + overlap for all but the last rank [ref: inference_cli.py:1082-1097]
+    assert P.segment_ranges(512, 8, 4) == [(64 * r, 64 * (r + 1) + (4 if r < 7 else 0)) for r in range(8)]
+    assert P.segment_ranges(10, 3, 0) == [(0, 4), (4, 7), (7, 10)]
+    assert P.segment_ranges(10, 1, 4) == [(0, 10)]
+    # pre-loaded split rounds the chunk up to a multiple of batch_size [ref: inference_cli.py:1118-1133]
+    assert P.segment_ranges(100, 2, 4, batch_size=5, streaming=False) == [(0, 55), (51, 100)]

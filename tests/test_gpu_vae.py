@@ -120,3 +120,30 @@ def test_pipeline_end_to_end_psnr(pkg, gpu):
     print(f"end-to-end PSNR vs fp32 oracle: hip={p_hip:.2f} dB, bf16 oracle={p_b16:.2f} dB, "
           f"max|d|={float((got - ref32).abs().max()):.4f}")
     assert p_hip >= p_b16 - 3.0 and p_hip > 30.0
+
+
+def test_runner_seam_and_node(pkg, gpu):
+    """The reference-shaped runner (vae_encode -> get_condition -> inference -> vae_decode) and the ComfyUI
+    node give the same pixels as the fused pipeline (same kernels underneath, no fallback path)."""
+    from seedvr2_ref import dit as odit
+    ovae, ocfg, vp, vae = _vae_pair(pkg, gpu, seed=1)
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=2, mm_layers=1, txt_in_dim=64, mlp_multiple_of=64)
+    dp = {k: bf(v) for k, v in odit.synthetic_params(odit.DiTConfig(**kw), 2).items()}
+    dit = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(**kw), dp, gpu)
+    txt = bf(torch.randn(58, 64, generator=torch.Generator().manual_seed(8)))
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    lr = torch.rand(5, 16, 24, 3, generator=torch.Generator().manual_seed(10))
+    x = pipe.transform(dev_bf16(lr, gpu), 32)                       # [T,Hp,Wp,3]
+    runner = pkg.infer.VideoDiffusionInfer()
+    runner.vae, runner.dit = vae, dit
+    runner.configure_diffusion()
+    lat = runner.vae_encode([x.permute(3, 0, 1, 2)])[0]
+    noise = pipe.make_noise(lat.shape, 42).to(gpu)
+    cond = runner.get_condition(noise, lat, "sr")
+    x0 = runner.inference([noise], [cond], [pipe.text_pos], [pipe.text_pos])[0]
+    dec = runner.vae_decode([x0])[0]                                 # c t h w
+    ref = pipe.upscale_batch(dev_bf16(lr, gpu), 32, 42)
+    assert torch.equal(dec.permute(1, 2, 3, 0), ref)
+    out, = pkg.nodes.SeedVR2VideoUpscaler.execute(lr, {}, {}, 42, 32, 0, 5, False, 0, 1, "none", pipeline=pipe)
+    assert out.dtype == torch.float32 and out.device.type == "cpu" and out.shape == (5, 32, 48, 3)
+    assert out.min() >= 0 and out.max() <= 1
