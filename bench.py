@@ -210,13 +210,13 @@ def main():
             if prev_tail[0] is not None:  # blend with the previous batch's tail (same rank)
                 hip.blend_overlap(prev_tail[0], sample[:overlap].contiguous(), w_prev, prev_tail[0])
             if world > 1:                 # segment boundary: head frames go to the left neighbour
-                reqs = []
+                ops = []
                 recv = torch.empty_like(sample[:overlap])
                 if rank > 0:
-                    reqs.append(dist.isend(sample[:overlap].contiguous(), rank - 1))
+                    ops.append(dist.P2POp(dist.isend, sample[:overlap].contiguous(), rank - 1))
                 if rank < world - 1:
-                    reqs.append(dist.irecv(recv, rank + 1))
-                for r in reqs:
+                    ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
+                for r in dist.batch_isend_irecv(ops):
                     r.wait()
                 if rank < world - 1:
                     tail = sample[-overlap:].contiguous()
