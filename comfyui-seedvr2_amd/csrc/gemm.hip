@@ -61,81 +61,89 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> LDS-DMA base stays scalar
     int tm, tn;
     tile_coords(a, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- loader setup: this thread moves 4 A rows and 4 W rows (16 bytes each) per K-tile.
     const int lrow = lane >> 3, lpos = lane & 7;
-    const char* a_ptr[4];
-    const char* w_ptr[4];
-    int a_choff[4];
-    int cy[4], cx[4], ct[4];  // conv: output pixel of each row (scaled by stride), cy < -(1<<20) => row invalid
-    const char* zero = (const char*)a.zero;
+    const char* a_ptr[4];   // dense: running source pointer; conv: frame base + pixel offset of the current tap_t
+    const char* w_ptr[4];   // running weight pointer
+    int cy[4], cx[4], ct[4];        // conv: top-left input coordinate / first padded frame of each output row
+    long long rowoff[4];            // conv: byte offset of (cy, cx) inside a frame + this lane's chunk
+    const char* zsrc = (const char*)a.zero + lpos * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + lrow;
         const int chunk = lpos ^ ((r >> 1) & 7);
-        a_choff[i] = chunk * 16;
         w_ptr[i] = (const char*)(a.W + (long long)(n0 + r) * a.K) + chunk * 16;
         const int m = m0 + r;
         if (AMODE == A_DENSE) {
-            if (m < a.M) {
-                const long long src = a.a_rows ? (long long)a.a_rows[m] : (long long)m;
-                a_ptr[i] = (const char*)(a.A + src * a.lda) + chunk * 16;
-            } else {
-                a_ptr[i] = nullptr;
-            }
+            long long src = m;
+            if (a.a_rows) src = a.a_rows[m < a.M ? m : a.M - 1];
+            a_ptr[i] = (m < a.M) ? (const char*)(a.A + src * a.lda) + chunk * 16 : nullptr;
         } else {
+            const int mm = m < a.M ? m : 0;
+            const int x = mm % a.cg.Wo, t2 = mm / a.cg.Wo;
+            const int y = t2 % a.cg.Ho, t = t2 / a.cg.Ho;
+            cx[i] = x * a.cg.sw - a.cg.pad_w0;
+            cy[i] = (m < a.M) ? y * a.cg.sh - a.cg.pad_h0 : -(1 << 28);  // invalid row: never in range
+            ct[i] = t * a.cg.st;
+            rowoff[i] = (((long long)cy[i] * a.cg.Wi + cx[i]) * a.cg.Cin) * 2 + chunk * 16;
             a_ptr[i] = nullptr;
-            if (m < a.M) {
-                const int x = m % a.cg.Wo, t2 = m / a.cg.Wo;
-                const int y = t2 % a.cg.Ho, t = t2 / a.cg.Ho;
-                cx[i] = x * a.cg.sw - a.cg.pad_w0;
-                cy[i] = y * a.cg.sh - a.cg.pad_h0;
-                ct[i] = t * a.cg.st;
-            } else {
-                cx[i] = 0; cy[i] = -(1 << 28); ct[i] = 0;
-            }
         }
     }
-    // conv tap state
+    // conv tap state (wave-uniform scalars); K order is ((kt*kh + ky)*kw + kx)*Cin + c
     int tap_t = 0, tap_y = 0, tap_x = 0, tap_c = 0;
-
-    auto issue = [&](int kt, int stage) {
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sB = sA + TILE_BYTES;
+    const long long frame_bytes = (long long)a.cg.Hi * a.cg.Wi * a.cg.Cin * 2;
+    auto set_frame = [&]() {  // a_ptr[i] = base of padded frame (ct[i] + tap_t) + rowoff[i]; runs when tap_t changes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const char* src;
-            if (AMODE == A_DENSE) {
-                src = a_ptr[i] ? a_ptr[i] + (long long)kt * (BK * 2) : zero + lpos * 16;
-            } else {
-                const int iy = cy[i] + tap_y, ix = cx[i] + tap_x, it = ct[i] + tap_t;
-                const bool ok = (iy >= 0) & (iy < a.cg.Hi) & (ix >= 0) & (ix < a.cg.Wi);
-                const long long frame_elems = (long long)a.cg.Hi * a.cg.Wi * a.cg.Cin;
-                const char* fbase;
-                if (it < a.cg.npad)
-                    fbase = a.cg.carry ? (const char*)(a.cg.carry + (long long)it * frame_elems) : (const char*)a.A;
-                else
-                    fbase = (const char*)(a.A + (long long)(it - a.cg.npad) * frame_elems);
-                const long long off = ((long long)iy * a.cg.Wi + ix) * a.cg.Cin + tap_c;
-                src = ok ? fbase + off * 2 + a_choff[i] : zero + lpos * 16;
-            }
-            glds16(src, sA + (wave * 4 + i) * 1024);
+            const int it = ct[i] + tap_t;
+            const bool head = it < a.cg.npad;
+            const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
+            const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+            a_ptr[i] = base + fidx * frame_bytes + rowoff[i];
         }
+    };
+    if (AMODE == A_CONV) set_frame();
+
+    auto issue = [&](int stage) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sB = sA + TILE_BYTES;
+        if (AMODE == A_DENSE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(w_ptr[i] + (long long)kt * (BK * 2), sB + (wave * 4 + i) * 1024);
-        if (AMODE == A_CONV) {  // advance the filter tap: K order is ((kt*kh + ky)*kw + kx)*Cin + c
+            for (int i = 0; i < 4; ++i) {
+                glds16(a_ptr[i] ? a_ptr[i] : zsrc, sA + (wave * 4 + i) * 1024);
+                if (a_ptr[i]) a_ptr[i] += BK * 2;
+            }
+        } else {
+            const long long toff = (((long long)tap_y * a.cg.Wi + tap_x) * a.cg.Cin + tap_c) * 2;  // scalar
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = ((unsigned)(cy[i] + tap_y) < (unsigned)a.cg.Hi) & ((unsigned)(cx[i] + tap_x) < (unsigned)a.cg.Wi);
+                const char* src = a_ptr[i] + toff;
+                glds16(ok ? src : zsrc, sA + (wave * 4 + i) * 1024);
+            }
             tap_c += BK;
             if (tap_c == a.cg.Cin) {
                 tap_c = 0;
                 if (++tap_x == a.cg.kw) {
                     tap_x = 0;
-                    if (++tap_y == a.cg.kh) { tap_y = 0; ++tap_t; }
+                    if (++tap_y == a.cg.kh) {
+                        tap_y = 0;
+                        ++tap_t;
+                        set_frame();
+                    }
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(w_ptr[i], sB + (wave * 4 + i) * 1024);
+            w_ptr[i] += BK * 2;
         }
     };
 
@@ -150,11 +158,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / BK;
-    issue(0, 0);
+    issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt landed for every wave; every wave is done reading stage (kt+1)&1
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk) issue((kt + 1) & 1);
         const char* sA = smem + (kt & 1) * STAGE_BYTES;
         const char* sB = sA + TILE_BYTES;
 #pragma unroll
