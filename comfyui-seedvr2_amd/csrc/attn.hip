@@ -1,14 +1,19 @@
-// Variable-length (per-window) flash attention, head_dim 128, bf16 in/out, fp32 softmax/accumulate.
+// Variable-length flash attention for gfx950, bf16 in/out, fp32 softmax/accumulate: the NaDiT window
+// attention (20/24 heads x 128, sequences = [window tokens ; text tokens]).  (The VAE's d=512 attention
+// lives in vae.hip: at 512 dims a 32-query wave needs 384+ live registers and spills, measured 8x slower
+// than the 16-query 16x16x32 form used there.)
 //
-// One 256-thread workgroup = 128 queries of one (window, head); each of the 4 waves owns 32 queries and
-// walks the window's keys in tiles of 64.  K and V tiles are staged by direct global->LDS loads
-// (2-deep ring, next tile in flight during the current one).  Matrix work uses v_mfma_f32_32x32x16_bf16
-// in the "swapped" orientation:
+// One 256-thread workgroup = 128 queries of one (sequence, head); each of the 4 waves owns 32 queries and
+// walks the sequence's keys in tiles of KT.  K and V tiles are staged by direct global->LDS loads
+// (2-deep ring, next tile in flight during the current one).  Matrix work is v_mfma_f32_32x32x16_bf16 in
+// the "swapped" orientation:
 //     S^T[key][query] = K . Q^T      (A = K fragment from LDS, B = Q fragment held in registers)
 //     O^T[d][query]  += V^T . P^T    (A = V^T via ds_read_b64_tr_b16, B = P^T straight from the S^T
 //                                     accumulators: no LDS round trip, no cross-lane traffic for P)
 // so a lane owns one query column: running max / sum / rescale are per-lane scalars; the two lanes
-// (l, l^32) that share a query exchange only their tile maxima.
+// (l, l^32) that share a query exchange only their tile maxima.  VALU diet per tile: the softmax scale is
+// folded into one FMA feeding v_exp, key masking runs only on a sequence's last tile, and the O^T rescale is
+// deferred until some query's maximum grows by more than 2^RESCALE_THR (wave-uniform branch).
 // LDS images are lane-linear (DMA), swizzled through the per-lane source address:
 //     K: 16-byte chunk ^= key & 15          (row reads by ds_read_b128: conflict-free)
 //     V: 16-byte chunk ^= (key & 3) << 2    (4-key x 16-col transposed reads: conflict-free)
@@ -16,62 +21,89 @@
 
 namespace {
 
-constexpr int HD = 128, QT = 128, KT = 64, NTH = 256;
-constexpr int KV_TILE_BYTES = KT * HD * 2;  // 16 KiB
-constexpr int ATT_LDS = 4 * KV_TILE_BYTES;  // K[2] + V[2] = 64 KiB
+constexpr int QT = 128, NTH = 256;
+constexpr float RESCALE_THR = 4.0f;  // log2 units: P stays <= 16 between rescales
 
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v; bf16* out;
     const int32_t* cu; const int32_t* tile_seq; const int32_t* tile_q0;
-    int H;
+    long long ld, ldo;   // elements between consecutive positions (q/k/v and out)
+    int fixed_len;       // > 0: sequences are frames of this length (cu/tile tables unused)
     float scale_log2;
 };
 
-__global__ __launch_bounds__(NTH) void window_attn_kernel(const AttnArgs a) {
+template <int HD, int KT>
+__global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(const AttnArgs a) {
+    constexpr int RB = HD * 2;            // bytes per K/V row
+    constexpr int CPR = RB / 16;          // 16-byte chunks per row
+    constexpr int KPI = 1024 / RB > 0 ? 1024 / RB : 1;  // keys per 1-KiB DMA instruction
+    constexpr int TILE_BYTES = KT * RB;
+    constexpr int NI = TILE_BYTES / 1024 / 4;  // DMA instructions per wave per tile (K or V)
+    constexpr int NKS = HD / 16, NDT = HD / 32, NK2 = KT / 32;
+    static_assert(RB <= 1024 && TILE_BYTES % 4096 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.y;
-    const int seq = a.tile_seq[blockIdx.x], q0 = a.tile_q0[blockIdx.x];
-    const int s0 = a.cu[seq], len = a.cu[seq + 1] - s0;
-    const long long rstride = (long long)a.H * HD;  // elements between consecutive positions
+    int q0, len;
+    long long s0;
+    if (a.fixed_len > 0) {
+        s0 = (long long)blockIdx.z * a.fixed_len; len = a.fixed_len; q0 = blockIdx.x * QT;
+    } else {
+        const int seq = a.tile_seq[blockIdx.x];
+        q0 = a.tile_q0[blockIdx.x];
+        s0 = a.cu[seq]; len = a.cu[seq + 1] - (int)s0;
+    }
     const int l31 = lane & 31, hh = lane >> 5;
+    const long long hoff = (long long)head * HD;
 
-    // ---- Q fragments (B operand): lane = (query l31, k-half hh), 8 k-steps of 16 dims
-    bf16x8 qf[8];
+    // ---- Q fragments (B operand): lane = (query l31, k-half hh), NKS k-steps of 16 dims
+    bf16x8 qf[NKS];
     {
         int qr = q0 + wave * 32 + l31;
         if (qr > len - 1) qr = len - 1;
-        const bf16* qp = a.q + ((long long)(s0 + qr) * a.H + head) * HD + hh * 8;
+        const bf16* qp = a.q + (s0 + qr) * a.ld + hoff + hh * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
 
-    // ---- K/V tile loader: wave w, instruction i moves keys (w*4+i)*4 .. +3 (4 x 256 B)
-    const int lkey = lane >> 4, lpos = lane & 15;
+    // ---- K/V tile loader: DMA instruction g = wave*NI + i moves KPI keys (1 KiB)
+    const int lkey = lane / CPR, lslot = lane % CPR;
     auto issue = [&](int t, int stage) {
-        char* sK = smem + stage * KV_TILE_BYTES;
-        char* sV = smem + (2 + stage) * KV_TILE_BYTES;
+        char* sK = smem + stage * TILE_BYTES;
+        char* sV = smem + (2 + stage) * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = (wave * 4 + i) * 4 + lkey;
+        for (int i = 0; i < NI; ++i) {
+            const int key = (wave * NI + i) * KPI + lkey;
             int kr = t * KT + key;
             if (kr > len - 1) kr = len - 1;
-            const long long row = ((long long)(s0 + kr) * a.H + head) * HD;
-            glds16(a.k + row + ((lpos ^ (key & 15)) << 3), sK + (wave * 4 + i) * 1024);
-            glds16(a.v + row + ((lpos ^ ((key & 3) << 2)) << 3), sV + (wave * 4 + i) * 1024);
+            const long long row = (s0 + kr) * a.ld + hoff;
+            glds16(a.k + row + ((lslot ^ (key & 15)) << 3), sK + (wave * NI + i) * 1024);
+            glds16(a.v + row + ((lslot ^ ((key & 3) << 2)) << 3), sV + (wave * NI + i) * 1024);
         }
     };
 
-    f32x16 oacc[4];
+    f32x16 oacc[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // m_run in raw score units (before the softmax scale)
+    const float c = a.scale_log2;
 
     // transposed-read lane constants: 16-lane group g -> d block, lane i -> (key row i>>2, cols 4*(i&3))
     const int tg = (lane >> 4) & 1, ti = lane & 15;
     const int tq = ti >> 2, tp = ti & 3;
+    // Swizzled LDS offsets split into a lane-dependent table indexed by the low bits of the k-step / d-tile
+    // and a compile-time part that folds into the ds_read offset field (keeps address VGPRs to 8 + 4):
+    //   K chunk (2ks+hh) ^ (key&15)      = (((ks&7) ^ (key>>1&7)) << 1 | (hh ^ (key&1)))  + 16*(ks>>3)
+    //   V chunk (4dt+2tg+(tp>>1)) ^ ((key&3)<<2) = (((dt&3) ^ (key&3)) << 2 | 2tg | tp>>1) + 16*(dt>>2)
+    int koff[8], voff[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) koff[j] = l31 * RB + (((((j ^ (l31 >> 1)) & 7) << 1) | (hh ^ (l31 & 1))) << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        voff[j] = (4 * hh + tq) * RB + (((((j ^ tq) & 3) << 2) | (2 * tg) | (tp >> 1)) << 4) + (tp & 1) * 8;
 
     const int nt = (len + KT - 1) / KT;
     issue(0, 0);
@@ -79,76 +111,80 @@ __global__ __launch_bounds__(NTH) void window_attn_kernel(const AttnArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        const char* sK = smem + (t & 1) * KV_TILE_BYTES;
-        const char* sV = smem + (2 + (t & 1)) * KV_TILE_BYTES;
+        const char* sK = smem + (t & 1) * TILE_BYTES;
+        const char* sV = smem + (2 + (t & 1)) * TILE_BYTES;
 
-        // ---- S^T = K . Q^T  (two 32-key halves)
-        f32x16 sacc[2];
+        // ---- S^T = K . Q^T  (32-key halves)
+        f32x16 sacc[NK2];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < NK2; ++k2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
-            const int key = k2 * 32 + l31;
-            const char* kp = sK + key * 256;
+            const char* kp = sK + k2 * 32 * RB;   // key = k2*32 + l31: (key & 15) == (l31 & 15)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kp + (((2 * ks + hh) ^ (key & 15)) << 4));
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kp + koff[ks & 7] + (ks >> 3) * 256);
                 sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
+                if (HD > 128 && (ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bound the live K fragments
             }
         }
 
         // ---- online softmax; this lane holds keys (r&3) + 8*(r>>2) + 4*hh (+32*k2) of its query
-        const int kbase = t * KT + 4 * hh;
-        float mx = -INFINITY;
+        if (t == nt - 1 && (len % KT) != 0) {  // only a sequence's last tile can hold padding keys
+            const int kbase = t * KT + 4 * hh;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+            for (int k2 = 0; k2 < NK2; ++k2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kidx = kbase + k2 * 32 + (r & 3) + 8 * (r >> 2);
-                float sv = sacc[k2][r] * a.scale_log2;
-                sv = kidx < len ? sv : -INFINITY;
-                sacc[k2][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) >= len) sacc[k2][r] = -INFINITY;
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[k2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pf[2][2];
+        // deferred rescale: P = 2^(c*(s - m_run)) is allowed to reach 2^RESCALE_THR before m_run moves
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > RESCALE_THR) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
+        bf16x8 pf[NK2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[k2][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[k2][r], c, -mc));
                 psum += p;
                 pf[k2][r >> 3][r & 7] = f2bf(p);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        for (int k2 = 0; k2 < NK2; ++k2)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int key0 = k2 * 32 + 16 * s + 4 * hh + tq;  // first 4-key block; second is +8
+                // key0 = k2*32 + 16*s + 4*hh + tq is the first 4-key block (key0 & 3 == tq); the second is +8
+                const char* vrow = sV + (k2 * 32 + 16 * s) * RB;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int chunk = dt * 4 + 2 * tg + (tp >> 1);
-                    const char* p0 = sV + key0 * 256 + ((chunk ^ ((key0 & 3) << 2)) << 4) + (tp & 1) * 8;
-                    const char* p1 = p0 + 8 * 256;  // key0 + 8 has the same (key & 3)
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const char* p0 = vrow + voff[dt & 3] + (dt >> 2) * 256;
                     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                         (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
                     const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p1));
-                    bf16x8 vf;
-                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                        (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 8 * RB));  // key0+8: same key&3
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                     oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[k2][s], oacc[dt], 0, 0, 0);
+                    if (HD > 128 && (dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live V fragments
                 }
             }
     }
@@ -158,9 +194,9 @@ __global__ __launch_bounds__(NTH) void window_attn_kernel(const AttnArgs a) {
     const float inv = 1.0f / l_tot;
     const int qr = q0 + wave * 32 + l31;
     if (qr < len) {
-        bf16* op = a.out + ((long long)(s0 + qr) * a.H + head) * HD + 4 * hh;
+        bf16* op = a.out + (s0 + qr) * a.ldo + hoff + 4 * hh;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4 o;
@@ -171,26 +207,35 @@ __global__ __launch_bounds__(NTH) void window_attn_kernel(const AttnArgs a) {
     }
 }
 
+template <int HD, int KT>
+int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int LDS = 4 * KT * HD * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "flash_attn: cannot reserve %d bytes of LDS", LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((flash_attn_kernel<HD, KT>), grid, dim3(NTH), LDS, s, a);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
 }  // namespace
 
 extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens,
                                 const int32_t* tile_seq, const int32_t* tile_q0, int32_t ntiles, int32_t H, int32_t D,
                                 float scale, void* stream) {
     SVR2_CHECK(q && k && v && out && cu_seqlens && tile_seq && tile_q0, SVR2_E_ARG, "svr2_window_attn: null pointer");
-    SVR2_CHECK(D == HD, SVR2_E_SHAPE, "svr2_window_attn: head_dim must be 128 (got %d)", D);
+    SVR2_CHECK(D == 128, SVR2_E_SHAPE, "svr2_window_attn: head_dim must be 128 (got %d)", D);
     SVR2_CHECK(ntiles > 0 && H > 0 && H <= 65535, SVR2_E_SHAPE, "svr2_window_attn: bad ntiles/H");
     SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
                "svr2_window_attn: pointers must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)window_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-        attr_set = true;
-    }
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
-    a.cu = cu_seqlens; a.tile_seq = tile_seq; a.tile_q0 = tile_q0; a.H = H;
+    a.cu = cu_seqlens; a.tile_seq = tile_seq; a.tile_q0 = tile_q0;
+    a.ld = (long long)H * 128; a.ldo = a.ld; a.fixed_len = 0;
     a.scale_log2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(window_attn_kernel, dim3(ntiles, H), dim3(NTH), ATT_LDS, (hipStream_t)stream, a);
-    SVR2_LAUNCH_CHECK();
-    return SVR2_OK;
+    return launch_attn<128, 64>(a, dim3(ntiles, H, 1), (hipStream_t)stream);
 }

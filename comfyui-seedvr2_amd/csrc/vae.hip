@@ -1,6 +1,5 @@
-// VAE-side kernels: per-frame GroupNorm (+SiLU) and the single-head d=512 spatial attention of the
-// mid block.  GroupNorm is HBM-bound (2 reads + 1 write of the activation); the attention is a flash
-// kernel on v_mfma_f32_16x16x32_bf16 in the same swapped orientation as csrc/attn.hip.
+// VAE-side kernels: per-frame GroupNorm (+SiLU), HBM-bound (2 reads + 1 write of the activation).
+// (The mid-block d=512 spatial attention is the <512,32> instance of csrc/attn.hip.)
 #include "common.h"
 
 namespace {
@@ -124,7 +123,8 @@ struct Attn5Args {
 
 __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const long long s0 = (long long)blockIdx.y * a.P;
     const int q0 = blockIdx.x * QB5;
@@ -158,6 +158,13 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     for (int dt = 0; dt < 32; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     const int tq = l15 >> 2, tp = l15 & 3;
+    // lane-dependent swizzled offsets (tables of 4 / 8) + compile-time parts folded into ds_read offsets
+    int koff[4], voff[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) koff[j] = l15 * 1024 + (((((j ^ (l15 >> 2)) & 3) << 2) | (kq ^ (l15 & 3))) << 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        voff[j] = (4 * kq + tq) * 1024 + (((((j ^ (4 * kq + tq)) & 7) << 1) | (tp >> 1)) << 4) + (tp & 1) * 8;
 
     const int nt = (len + KB5 - 1) / KB5;
     issue(0, 0);
@@ -172,59 +179,60 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             sacc[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int key = k2 * 16 + l15;
-            const char* kp = sK + key * 1024;
+            const char* kp = sK + k2 * 16 * 1024;   // key = k2*16 + l15: (key & 15) == l15
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kp + (((4 * ks + kq) ^ (key & 15)) << 4));
+                const bf16x8 kf = *(const bf16x8*)(kp + koff[ks & 3] + (ks >> 2) * 256);
                 sacc[k2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // lane holds keys 16*k2 + 4*kq + r of query l15
-        float mx = -INFINITY;
+        if (t == nt - 1 && (len % KB5) != 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t * KB5 + k2 * 16 + 4 * kq + r >= len) sacc[k2][r] = -INFINITY;
+        }
+        float mx = sacc[0][0];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kidx = t * KB5 + k2 * 16 + 4 * kq + r;
-                float sv = sacc[k2][r] * a.scale_log2;
-                sv = kidx < len ? sv : -INFINITY;
-                sacc[k2][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[k2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        const float c = a.scale_log2;
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > 4.0f) != 0) {  // deferred rescale (see attn.hip)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 32; ++dt) oacc[dt] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         bf16x8 pf;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[k2][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[k2][r], c, -mc));
                 psum += p;
                 pf[k2 * 4 + r] = f2bf(p);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 32; ++dt) oacc[dt] *= alpha;
+        l_run += psum;
 
-        const int key0 = 4 * kq + tq;
-        const char* vrow = sV + key0 * 1024 + (tp & 1) * 8;
-        const int vswz = (key0 & 7) << 1;
 #pragma unroll
         for (int dt = 0; dt < 32; ++dt) {
-            const int chunk = dt * 2 + (tp >> 1);
-            const char* p0 = vrow + ((chunk ^ vswz) << 4);
+            const char* p0 = sV + voff[dt & 7] + (dt >> 3) * 256;
             const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
             const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                 (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 16 * 1024));
-            bf16x8 vf;
-            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+            const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -297,7 +305,7 @@ extern "C" int svr2_groupnorm_apply(const void* x, const float* coef, void* y, i
 }
 
 extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo,
-                              int32_t frames, int32_t P, float scale, void* stream) {
+                                  int32_t frames, int32_t P, float scale, void* stream) {
     SVR2_CHECK(q && k && v && out, SVR2_E_ARG, "svr2_attn_d512: null pointer");
     SVR2_CHECK(frames > 0 && frames <= 65535 && P > 0 && ld >= D5 && ldo >= D5 && ld % 8 == 0 && ldo % 8 == 0,
                SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
@@ -313,8 +321,8 @@ extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64
     Attn5Args a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
     a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_d512_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream,
-                       a);
+    hipLaunchKernelGGL(attn_d512_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS,
+                       (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

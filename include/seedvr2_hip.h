@@ -202,6 +202,7 @@ int svr2_groupnorm_apply(const void* x, const float* coef, void* y, int32_t F, i
 int svr2_attn_d512(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo,
                    int32_t frames, int32_t P, float scale, void* stream);
 
+
 /* ------------------------------------------------------------------ pixel-space stages
  * Antialiased bicubic resize (separable taps computed by the host exactly as ATen's
  * _upsample_bicubic2d_aa does), clamp to [0,1], zero-pad bottom/right to (Hp, Wp), (x-0.5)/0.5

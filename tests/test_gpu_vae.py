@@ -38,6 +38,7 @@ def test_groupnorm_silu(pkg, gpu, Fr, H, W, C, silu):
 @pytest.mark.parametrize("frames,P", [(2, 200), (1, 4096), (3, 129)])
 def test_attn_d512(pkg, gpu, frames, P):
     qkv = rnd(frames * P, 1536, seed=4)
+    qkv[7, 512:1024] = qkv[3, :512] * 2.0  # a key aligned with a query: forces a late max jump (rescale path)
     out = pkg.hip.attn_d512(dev_bf16(qkv, gpu), frames, P).float().cpu()
     q, k, v = (qkv[:, i * 512:(i + 1) * 512].reshape(frames, P, 512) for i in range(3))
     ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(512), dim=-1) @ v

@@ -20,6 +20,7 @@ hip.device_check(0)
 
 
 def timeit(fn, iters=10, warm=2):
+    iters = int(os.environ.get('SVR2_KB_ITERS', iters)); warm = int(os.environ.get('SVR2_KB_WARM', warm))
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -57,7 +58,7 @@ def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3)):
     b = torch.zeros(Cout, device=dev)
     out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
     fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out)
-    t = timeit(fn, iters=5, warm=1)
+    t = timeit(fn)
     fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
     print(f"conv3d T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
@@ -70,10 +71,18 @@ def bench_attn(grid, method, H=20):
     cu, ts, tq = up(pl.cu_seqlens), up(pl.tile_seq), up(pl.tile_q0)
     out = torch.empty_like(q)
     fn = lambda: hip.window_attn(q, k, v, cu, ts, tq, 1 / math.sqrt(128), out)
-    t = timeit(fn, iters=5, warm=1)
+    t = timeit(fn)
     lens = np.diff(pl.cu_seqlens).astype(np.float64)
     fl = 4 * 128 * (lens ** 2).sum() * H
     print(f"window_attn grid={grid} {method[:7]} S={S} nwin={pl.nwin}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
+
+
+def bench_attn512(frames, P):
+    qkv = rb(frames * P, 1536)
+    out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
+    for var in ("v16",):
+        t = timeit(lambda: hip.attn_d512(qkv, frames, P, out), iters=3, warm=1)
+        print(f"attn_d512[{var}] frames={frames} P={P}: {t*1e3:.3f} ms  {4*512*P*P*frames/t/1e12:.1f} TFLOP/s", flush=True)
 
 
 def bench_norm(rows, dim):
@@ -93,6 +102,11 @@ if __name__ == "__main__":
             bench_gemm(M, 13824, 2560, "swiglu")
             bench_gemm(M, 2560, 6912, "gate")
         bench_gemm(8192, 8192, 8192)
+    if "pmc" in which:  # one launch of each hot kernel shape for counter collection
+        bench_gemm(162000, 7680, 2560)
+        bench_conv(5, 272, 480, 512, 512)
+        bench_conv(4, 2160, 3840, 128, 128)
+        bench_attn((5, 135, 240), pkg.windows.REGULAR)
     if "conv" in which:
         bench_conv(5, 136, 240, 512, 512)
         bench_conv(5, 272, 480, 512, 512)
@@ -103,5 +117,8 @@ if __name__ == "__main__":
         bench_attn((3, 68, 120), pkg.windows.REGULAR)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
         bench_attn((5, 135, 240), pkg.windows.SHIFTED)
+    if "attn512" in which:
+        bench_attn512(2, 32640)
+        bench_attn512(1, 129600)
     if "norm" in which:
         bench_norm(162000, 2560)
