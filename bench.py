@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg3": (21, 720, 1280, 2160, 4, "SeedVR2-3B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[2])"),
     "cfg2": (9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8(+1 pad)-frame 540p->1080p (BASELINE configs[1])"),
     "cfg1": (1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
+    "cfg4": (21, 720, 1280, 2160, 4, "SeedVR2-7B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[3])"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
@@ -69,16 +70,27 @@ class KernelTimer:
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            self.pairs.append((e0, e1))
-            self.flops += flop_fn(out, *a, **k)
+            f = flop_fn(out, *a, **k)
+            self.pairs.append((e0, e1, f, (tuple(a[0].shape), tuple(out.shape), a[3], k.get("carry") is not None,
+                                           k.get("resid") is not None)))
+            self.flops += f
             return out
         return inner
 
     def summary(self):
         if not self.pairs:
             return 0, 0.0, 0.0
-        t = sum(a.elapsed_time(b) for a, b in self.pairs) * 1e-3
+        t = sum(p[0].elapsed_time(p[1]) for p in self.pairs) * 1e-3
         return len(self.pairs), t, self.flops
+
+    def table(self):
+        import collections
+        agg = collections.OrderedDict()
+        for e0, e1, f, key in self.pairs:
+            d = agg.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return [f"{k}: calls={v[0]} time={v[1]*1e3:.1f}ms {v[2]/v[1]/1e12:.0f} TFLOP/s" for k, v in rows]
 
 
 def cpu_baseline(workload, n_threads):
@@ -147,9 +159,11 @@ def _vae_flops(T, H, W):
     return enc, dec
 
 
-def _dit_flops(T, H, W):
+def _dit_flops(T, H, W, model="3b"):
     Tl = (T - 1) // 4 + 1
     L = Tl * (H // 16) * (W // 16)
+    if model == "7b":
+        return 36 * 2.0 * L * (3072 * 9216 + 3072 * 3072 + 2 * 3072 * 12288)
     return 32 * 2.0 * L * (2560 * 7680 + 2560 * 2560 + 3 * 2560 * 6912)  # GEMMs only (95 % of the DiT)
 
 
@@ -182,7 +196,7 @@ def main():
     t_build = time.time()
     vcfg = pkg.vae.VAEConfig()
     vae = pkg.vae.VideoVAEHip(vcfg, pkg.vae.synthetic_state_dict(vcfg, dev, seed=1), dev)
-    dcfg = pkg.dit.CFG_3B
+    dcfg = pkg.dit.CFG_7B if args.workload == "cfg4" else pkg.dit.CFG_3B
     dit = pkg.dit.NaDiTHip(dcfg, pkg.dit.synthetic_state_dict(dcfg, dev, seed=2), dev)
     gtxt = torch.Generator(device="cpu").manual_seed(3)
     text_pos = (0.5 * torch.randn(58, 5120, generator=gtxt)).to(torch.bfloat16)  # shape of the shipped pos_emb.pt
@@ -252,8 +266,11 @@ def main():
 
     if rank == 0:
         nl, kt, kf = ktimer.summary()
+        if os.environ.get("SVR2_BENCH_TABLE"):
+            for line in ktimer.table():
+                log("  conv3d", line)
         enc_f, dec_f = _vae_flops(T, ph, pw)
-        dit_f = _dit_flops(T, ph, pw)
+        dit_f = _dit_flops(T, ph, pw, "7b" if args.workload == "cfg4" else "3b")
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
         result = {
             "metric": "upscaled frames/sec + peak HBM GB, SeedVR2-3B 720p->4K, 1/2/4/8 MI355X",

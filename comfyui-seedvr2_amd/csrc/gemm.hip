@@ -12,13 +12,25 @@
 // every epilogue works on 8 consecutive columns and stores 16 bytes per lane, whole 256-byte rows.
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // 64 KiB, reused as the fp32 [128][128] epilogue tile
+constexpr int BN = 128, BK = 64;
+constexpr int B_TILE_BYTES = BN * BK * 2;         // 16 KiB
+// Two tile geometries share one kernel body (template parameter BM):
+//   BM = 128: 4 waves (2 x 2), 2-deep LDS ring (64 KiB), 2 workgroups per CU  - small problems / tails
+//   BM = 256: 8 waves (4 x 2), 3-deep LDS ring (144 KiB), counted vmcnt: two K-tiles of DMA stay in flight
+//             across the barrier, W traffic per FLOP halves                    - the large GEMMs / convs
+template <int BM> struct Geo {
+    static constexpr int NT = BM * 2;                       // threads
+    static constexpr int NW = NT / 64;                      // waves
+    static constexpr int STAGES = BM == 256 ? 3 : 2;
+    static constexpr int A_TILE_BYTES = BM * BK * 2;
+    static constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // >= BM*BN*4 (fp32 epilogue tile)
+    static constexpr int NBI = 16 / NW;                     // W DMA instructions per wave per K-tile
+};
 constexpr int GROUP_M = 8;                        // band height (in tiles) of the L2-friendly tile order
 
 enum AMode { A_DENSE = 0, A_CONV = 1 };
@@ -58,8 +70,11 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
     tn = rem / rows;
 }
 
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
+template <int AMODE, int EPI, int BM>
+__global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
+    using G = Geo<BM>;
+    constexpr int NTHREADS = G::NT, STAGE_BYTES = G::STAGE_BYTES, TILE_BYTES = G::A_TILE_BYTES, NBI = G::NBI;
+    static_assert(G::LDS_BYTES >= BM * BN * 4, "epilogue tile must fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> LDS-DMA base stays scalar
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
     // ---- loader setup: this thread moves 4 A rows and 4 W rows (16 bytes each) per K-tile.
     const int lrow = lane >> 3, lpos = lane & 7;
     const char* a_ptr[4];   // dense: running source pointer; conv: frame base + pixel offset of the current tap_t
-    const char* w_ptr[4];   // running weight pointer
+    const char* w_ptr[NBI]; // running weight pointer
     int cy[4], cx[4], ct[4];        // conv: top-left input coordinate / first padded frame of each output row
     long long rowoff[4];            // conv: byte offset of (cy, cx) inside a frame + this lane's chunk
     const char* zsrc = (const char*)a.zero + lpos * 16;
@@ -78,7 +93,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + lrow;
         const int chunk = lpos ^ ((r >> 1) & 7);
-        w_ptr[i] = (const char*)(a.W + (long long)(n0 + r) * a.K) + chunk * 16;
         const int m = m0 + r;
         if (AMODE == A_DENSE) {
             long long src = m;
@@ -94,6 +108,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
             rowoff[i] = (((long long)cy[i] * a.cg.Wi + cx[i]) * a.cg.Cin) * 2 + chunk * 16;
             a_ptr[i] = nullptr;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int r = (wave * NBI + i) * 8 + lrow;
+        w_ptr[i] = (const char*)(a.W + (long long)(n0 + r) * a.K) + ((lpos ^ ((r >> 1) & 7)) << 4);
     }
     // conv tap state (wave-uniform scalars); K order is ((kt*kh + ky)*kw + kx)*Cin + c
     int tap_t = 0, tap_y = 0, tap_x = 0, tap_c = 0;
@@ -141,14 +160,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(w_ptr[i], sB + (wave * 4 + i) * 1024);
+        for (int i = 0; i < NBI; ++i) {
+            glds16(w_ptr[i], sB + (wave * NBI + i) * 1024);
             w_ptr[i] += BK * 2;
         }
     };
 
     // ---- MFMA fragment addressing
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;   // waves are (BM/64) x 2
     const int frow = lane & 15, fq = lane >> 4;
     const int swz = (frow >> 1) & 7;
     f32x4 acc[4][4];
@@ -159,12 +178,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
 
     const int nk = a.K / BK;
     issue(0);
+    if (G::STAGES == 3 && nk > 1) issue(1);
+    int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile kt landed for every wave; every wave is done reading stage (kt+1)&1
-        if (kt + 1 < nk) issue((kt + 1) & 1);
-        const char* sA = smem + (kt & 1) * STAGE_BYTES;
+        // Tile kt must have landed for every wave, and every wave must be done reading the stage that is
+        // about to be refilled.  3-stage ring: leave the DMA of tile kt+1 in flight across the barrier
+        // (counted vmcnt = this thread's loads per tile); raw s_barrier, never __syncthreads (it drains vmcnt).
+        if (G::STAGES == 3) {
+            if (kt + 1 < nk) {
+                if (NBI == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (kt + 2 < nk) issue(stage >= 1 ? stage - 1 : 2);   // (kt + 2) % 3
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue(stage ^ 1);
+        }
+        const char* sA = smem + stage * STAGE_BYTES;
         const char* sB = sA + TILE_BYTES;
+        stage = (G::STAGES == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -243,6 +278,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
                 if (fo > 1) fo -= 1;
             }
             dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
+        } else if (EPI == SVR2_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {  // nn.GELU("tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+                const float x = v[e], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+                v[e] = x / (1.f + __expf(-2.f * u));   // 0.5 x (1 + tanh u) == x * sigmoid(2u)
+            }
+            dst = (long long)m * a.ldc + n;
         } else {
             if (a.resid) {  // conv residual add
                 const bf16x8 rv = *(const bf16x8*)(a.resid + (long long)m * a.ldr + n);
@@ -262,17 +304,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a) {
     }
 }
 
-template <int AMODE, int EPI>
-int launch(const KArgs& a, hipStream_t s) {
+template <int AMODE, int EPI, int BM>
+int launch_bm(KArgs a, hipStream_t s) {
+    using G = Geo<BM>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AMODE, EPI, BM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "gemm: cannot reserve %d bytes of LDS", G::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI>), dim3(a.nbm * a.nbn), dim3(NTHREADS), LDS_BYTES, s, a);
+    a.nbm = (a.M + BM - 1) / BM;
+    a.nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, BM>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS_BYTES, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
+}
+
+// Tile choice: 256-row tiles once the grid still fills the chip (>= 2 tiles per CU), else 128-row tiles.
+inline int g_force_bm() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SVR2_GEMM_BM");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+template <int AMODE, int EPI>
+int launch(const KArgs& a, hipStream_t s) {
+    const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
+    const int force = g_force_bm();
+    const bool big = force ? force == 256 : tiles256 >= 512;
+    return big ? launch_bm<AMODE, EPI, 256>(a, s) : launch_bm<AMODE, EPI, 128>(a, s);
 }
 
 }  // namespace
@@ -306,7 +369,7 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
     SVR2_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->K % BK == 0, SVR2_E_SHAPE,
                "svr2_gemm: need M,N,K > 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)d->M, (long long)d->N,
                (long long)d->K);
-    SVR2_CHECK(d->M < (1ll << 31) - BM && d->N < (1ll << 30), SVR2_E_SHAPE, "svr2_gemm: M/N too large");
+    SVR2_CHECK(d->M < (1ll << 31) - 256 && d->N < (1ll << 30), SVR2_E_SHAPE, "svr2_gemm: M/N too large");
     SVR2_CHECK(d->lda % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->W) && aligned16(d->C),
                SVR2_E_ALIGN, "svr2_gemm: A/W/C must be 16-byte aligned with lda, ldc %% 8 == 0");
     SVR2_CHECK(d->lda >= d->K, SVR2_E_SHAPE, "svr2_gemm: lda < K");
@@ -317,7 +380,6 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
     a.zero = (const bf16*)d->zero_page;
     a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
     a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
-    a.nbm = (a.M + BM - 1) / BM; a.nbn = (a.N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
     switch (d->epilogue) {
         case SVR2_EPI_BIAS:
@@ -342,6 +404,8 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
             SVR2_CHECK(!(d->ps_drop_head && d->ps_tz != 2), SVR2_E_SHAPE, "svr2_gemm: drop_head needs tz == 2");
             return launch<A_DENSE, SVR2_EPI_PIXSHUF3D>(a, s);
         }
+        case SVR2_EPI_GELU:
+            return launch<A_DENSE, SVR2_EPI_GELU>(a, s);
         default:
             svr2_set_error("svr2_gemm: unknown epilogue %d", d->epilogue);
             return SVR2_E_ARG;
@@ -368,14 +432,13 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
                    (!d->resid || aligned16(d->resid)),
                SVR2_E_ALIGN, "svr2_conv3d: pointers must be 16-byte aligned");
     const long long M = (long long)d->To * d->Ho * d->Wo;
-    SVR2_CHECK(M < (1ll << 31) - BM, SVR2_E_SHAPE, "svr2_conv3d: too many output pixels for one call");
+    SVR2_CHECK(M < (1ll << 31) - 256, SVR2_E_SHAPE, "svr2_conv3d: too many output pixels for one call");
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.A = (const bf16*)d->x; a.W = (const bf16*)d->w; a.C = (bf16*)d->y;
     a.bias = d->bias; a.resid = (const bf16*)d->resid; a.zero = (const bf16*)d->zero_page;
     a.ldc = d->Cout; a.ldr = d->Cout;
     a.M = (int)M; a.N = d->Cout; a.K = d->kt * d->kh * d->kw * d->Cin;
-    a.nbm = (a.M + BM - 1) / BM; a.nbn = (a.N + BN - 1) / BN;
     a.cg.carry = (const bf16*)d->carry;
     a.cg.T = d->T; a.cg.Hi = d->Hi; a.cg.Wi = d->Wi; a.cg.Cin = d->Cin;
     a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;

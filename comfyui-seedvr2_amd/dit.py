@@ -42,10 +42,16 @@ class DiTConfig:
     norm_eps: float = 1e-5
     window: Tuple[int, int, int] = (4, 3, 3)
     mlp_multiple_of: int = 256
-    rope_mode: int = 1  # 1 = 3B mm-rope ('lang'), 0 = none
+    rope_mode: int = 1  # 1 = 3B mm-rope ('lang'), 2 = 7B video-only 'pixel' rope, 0 = none
+    # 7B deltas [ref: src/models/dit_7b/nadit.py:39-190, configs_7b/main.yaml:11-34]
+    mlp_type: str = "swiglu"     # "swiglu" | "normal" (Linear+b -> GELU(tanh) -> Linear+b)
+    out_norm: bool = True        # vid_out_norm + vid_out_ada (3B only)
+    last_vid_only: bool = True   # 3B: last layer's mlp / ada are vid-only
 
     @property
     def mlp_hidden(self) -> int:
+        if self.mlp_type == "normal":
+            return self.vid_dim * self.expand_ratio  # [ref: dit_7b/mlp.py:34]
         hid = int(2 * self.vid_dim * self.expand_ratio / 3)  # [ref: dit_3b/mlp.py:54-55]
         m = self.mlp_multiple_of
         return m * ((hid + m - 1) // m)
@@ -58,6 +64,8 @@ class DiTConfig:
 
 
 CFG_3B = DiTConfig()
+CFG_7B = DiTConfig(vid_dim=3072, heads=24, num_layers=36, mm_layers=36, rope_mode=2, mlp_type="normal",
+                   out_norm=False, last_vid_only=False)
 
 
 def _timestep_embedding(t: float, dim: int = 256) -> torch.Tensor:
@@ -93,14 +101,15 @@ class NaDiTHip:
         self.b_txt_in = f32(params["txt_in.bias"])
         self.w_vid_out = hip.pad_weight(params["vid_out.proj.weight"].to(dev))
         self.b_vid_out = f32(params["vid_out.proj.bias"])
-        # vid_out_norm (affine) + vid_out_ada reuse of the attn-layer slice  [ref: nadit.py:234-244]
-        self.out_scale = (f32(params["vid_out_norm.weight"]) * (emb[:, 0, 1] + f32(params["vid_out_ada.out_scale"]))).contiguous()
-        self.out_shift = (emb[:, 0, 0] + f32(params["vid_out_ada.out_shift"])).contiguous()
+        if cfg.out_norm:
+            # vid_out_norm (affine) + vid_out_ada reuse of the attn-layer slice  [ref: nadit.py:234-244]
+            self.out_scale = (f32(params["vid_out_norm.weight"]) * (emb[:, 0, 1] + f32(params["vid_out_ada.out_scale"]))).contiguous()
+            self.out_shift = (emb[:, 0, 0] + f32(params["vid_out_ada.out_shift"])).contiguous()
 
         ones = torch.ones(d, dtype=torch.float32, device=dev)
         self.layers = []
         for i in range(cfg.num_layers):
-            last = i == cfg.num_layers - 1
+            last = cfg.last_vid_only and i == cfg.num_layers - 1
             bv, bt = ("all", "all") if cfg.shared(i) else ("vid", "txt")
             pre = f"blocks.{i}."
             L = {}
@@ -117,11 +126,14 @@ class NaDiTHip:
                 }
                 vid_only_skip = last and tag == "t"
                 if not vid_only_skip:
-                    ent.update({
-                        "w_gi": hip.pad_weight(hip.interleave_swiglu(g(f"mlp.{b}.proj_in_gate.weight").to(dev),
-                                                                     g(f"mlp.{b}.proj_in.weight").to(dev))),
-                        "w_mo": hip.pad_weight(g(f"mlp.{b}.proj_out.weight").to(dev)),
-                    })
+                    if cfg.mlp_type == "swiglu":
+                        ent["w_gi"] = hip.pad_weight(hip.interleave_swiglu(g(f"mlp.{b}.proj_in_gate.weight").to(dev),
+                                                                           g(f"mlp.{b}.proj_in.weight").to(dev)))
+                    else:
+                        ent["w_gi"] = hip.pad_weight(g(f"mlp.{b}.proj_in.weight").to(dev))
+                        ent["b_gi"] = f32(g(f"mlp.{b}.proj_in.bias"))
+                        ent["b_mo"] = f32(g(f"mlp.{b}.proj_out.bias"))
+                    ent["w_mo"] = hip.pad_weight(g(f"mlp.{b}.proj_out.weight").to(dev))
                     for li, lname in enumerate(("attn", "mlp")):
                         ent[f"{lname}_scale"] = (emb[:, li, 1] + f32(g(f"ada.{b}.{lname}_scale"))).contiguous()
                         ent[f"{lname}_shift"] = (emb[:, li, 0] + f32(g(f"ada.{b}.{lname}_shift"))).contiguous()
@@ -131,6 +143,7 @@ class NaDiTHip:
                 L[tag] = ent
             self.layers.append(L)
 
+        self._rope7 = {}
         # rope tables (3B): angle = pos * theta^(-2i/42), i < 21  [ref: dit_3b/rope.py:74-85]
         nfreq = (cfg.head_dim // 3) // 2
         fr = 1.0 / (10000.0 ** (torch.arange(0, cfg.head_dim // 3, 2)[:nfreq].float() / (cfg.head_dim // 3)))
@@ -161,10 +174,35 @@ class NaDiTHip:
             }
         return self._plans[key]
 
+    def _rope_tables_7b(self, grid, method: str, txt_len: int):
+        """Per-position cos/sin [S, 30] of the 7B 'pixel' rope: 10 freqs linspace(1,128,10)*pi per axis,
+        window-local positions linspace(-1,1,n); the reference casts the ANGLES to the activations' dtype
+        (bf16) before cos/sin [ref: src/models/dit_7b/rope.py:25-47,73-124]; text rows are not rotated."""
+        key = (grid, method, txt_len)
+        if key not in self._rope7:
+            p = W.plan(grid, method, txt_len, self.cfg.window)
+            nf = ((self.cfg.head_dim // 2) // 3) // 2
+            fr = torch.linspace(1.0, 256.0 / 2, nf) * math.pi
+            ang = torch.zeros(p.total, 3 * nf, dtype=torch.float32)
+            boxes = W.window_boxes(method, grid, self.cfg.window)
+            off = 0
+            for (t0, t1, h0, h1, w0, w1) in boxes:
+                f, hh, ww = t1 - t0, h1 - h0, w1 - w0
+                at = (torch.linspace(-1, 1, f)[:, None] * fr[None])[:, None, None, :].expand(f, hh, ww, nf)
+                ah = (torch.linspace(-1, 1, hh)[:, None] * fr[None])[None, :, None, :].expand(f, hh, ww, nf)
+                aw = (torch.linspace(-1, 1, ww)[:, None] * fr[None])[None, None, :, :].expand(f, hh, ww, nf)
+                n = f * hh * ww
+                ang[off:off + n] = torch.cat((at, ah, aw), dim=-1).reshape(n, 3 * nf)
+                off += n + txt_len
+            angq = ang.to(torch.bfloat16)
+            self._rope7[key] = (angq.cos().float().contiguous().to(self.device),
+                                angq.sin().float().contiguous().to(self.device))
+        return self._rope7[key]
+
     # ------------------------------------------------------------------ forward
     def block(self, i: int, x: torch.Tensor, y: torch.Tensor, grid, taps=None):
         cfg = self.cfg
-        last = i == cfg.num_layers - 1
+        last = cfg.last_vid_only and i == cfg.num_layers - 1
         Lv, Lt_ = self.layers[i]["v"], self.layers[i]["t"]
         H, D, d = cfg.heads, cfg.head_dim, cfg.vid_dim
         ntxt = y.shape[0]
@@ -174,8 +212,10 @@ class NaDiTHip:
         ya = hip.rmsnorm_mod(y, Lt_["attn_scale"], Lt_["attn_shift"], cfg.norm_eps)
         qkv_v = hip.gemm(xa, Lv["w_qkv"], 3 * H * D)
         qkv_t = hip.gemm(ya, Lt_["w_qkv"], 3 * H * D)
+        rc, rs = (self._rope_tables_7b(grid, cfg.method(i), ntxt) if cfg.rope_mode == 2
+                  else (self.rope_cos, self.rope_sin))
         qkvw = hip.qkv_prep(qkv_v, qkv_t, pl["src_row"], pl["pos"], Lv["qn"], Lv["kn"], Lt_["qn"], Lt_["kn"],
-                            self.rope_cos, self.rope_sin, H, cfg.rope_mode, cfg.norm_eps)
+                            rc, rs, H, cfg.rope_mode, cfg.norm_eps)
         del qkv_v, qkv_t, xa, ya
         o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D))
         del qkvw
@@ -188,14 +228,18 @@ class NaDiTHip:
             taps["x1"] = x1; taps["y1"] = y1
         del o, o2
         # mlp half
-        xm = hip.rmsnorm_mod(x1, Lv["mlp_scale"], Lv["mlp_shift"], cfg.norm_eps)
-        hmid = hip.gemm(xm, Lv["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
-        x2 = hip.gemm(hmid, Lv["w_mo"], d, epilogue=hip.EPI_GATE_RES, gate=Lv["mlp_gate"], resid=x1)
-        del xm, hmid
+        def mlp(h_in, Lp, resid):
+            hn = hip.rmsnorm_mod(h_in, Lp["mlp_scale"], Lp["mlp_shift"], cfg.norm_eps)
+            if cfg.mlp_type == "swiglu":
+                hmid = hip.gemm(hn, Lp["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
+            else:
+                hmid = hip.gemm(hn, Lp["w_gi"], cfg.mlp_hidden, epilogue=hip.EPI_GELU, bias=Lp["b_gi"])
+            return hip.gemm(hmid, Lp["w_mo"], d, epilogue=hip.EPI_GATE_RES, bias=Lp.get("b_mo"), gate=Lp["mlp_gate"],
+                            resid=resid)
+
+        x2 = mlp(x1, Lv, x1)
         if not last:
-            ym = hip.rmsnorm_mod(y1, Lt_["mlp_scale"], Lt_["mlp_shift"], cfg.norm_eps)
-            ht = hip.gemm(ym, Lt_["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
-            y2 = hip.gemm(ht, Lt_["w_mo"], d, epilogue=hip.EPI_GATE_RES, gate=Lt_["mlp_gate"], resid=y1)
+            y2 = mlp(y1, Lt_, y1)
         else:
             y2 = y1  # unused downstream
         return x2, y2
@@ -222,7 +266,7 @@ class NaDiTHip:
             x, y = self.block(i, x, y, grid, taps if (taps is not None and i == 0) else None)
             if taps is not None:
                 taps[f"x{i + 1}"] = x
-        xo = hip.rmsnorm_mod(x, self.out_scale, self.out_shift, cfg.norm_eps)
+        xo = hip.rmsnorm_mod(x, self.out_scale, self.out_shift, cfg.norm_eps) if cfg.out_norm else x
         pred = hip.gemm(xo, self.w_vid_out, cfg.vid_out_channels * 4, bias=self.b_vid_out)
         return hip.patch_out_x0(pred, noise)
 
@@ -245,11 +289,12 @@ def synthetic_state_dict(cfg: DiTConfig, device, seed: int = 0, dtype=torch.bflo
     out["emb_in.proj_in.weight"] = mat(d, 256); out["emb_in.proj_in.bias"] = vec(d)
     out["emb_in.proj_hid.weight"] = mat(d, d); out["emb_in.proj_hid.bias"] = vec(d)
     out["emb_in.proj_out.weight"] = mat(6 * d, d); out["emb_in.proj_out.bias"] = vec(6 * d)
-    out["vid_out_norm.weight"] = vec(d, 1.0, 0.1)
-    out["vid_out_ada.out_shift"] = vec(d, 0.0, 1 / math.sqrt(d)); out["vid_out_ada.out_scale"] = vec(d, 1.0, 1 / math.sqrt(d))
+    if cfg.out_norm:
+        out["vid_out_norm.weight"] = vec(d, 1.0, 0.1)
+        out["vid_out_ada.out_shift"] = vec(d, 0.0, 1 / math.sqrt(d)); out["vid_out_ada.out_scale"] = vec(d, 1.0, 1 / math.sqrt(d))
     out["vid_out.proj.weight"] = mat(cfg.vid_out_channels * 4, d); out["vid_out.proj.bias"] = vec(cfg.vid_out_channels * 4)
     for i in range(cfg.num_layers):
-        last = i == cfg.num_layers - 1
+        last = cfg.last_vid_only and i == cfg.num_layers - 1
         p = f"blocks.{i}."
         for b in (("all",) if cfg.shared(i) else ("vid", "txt")):
             out[p + f"attn.proj_qkv.{b}.weight"] = mat(3 * H * hd, d)
@@ -259,7 +304,11 @@ def synthetic_state_dict(cfg: DiTConfig, device, seed: int = 0, dtype=torch.bflo
             out[p + f"attn.norm_k.{b}.weight"] = vec(hd, 1.0, 0.1)
             if last and b == "txt":
                 continue
-            out[p + f"mlp.{b}.proj_in_gate.weight"] = mat(cfg.mlp_hidden, d)
+            if cfg.mlp_type == "swiglu":
+                out[p + f"mlp.{b}.proj_in_gate.weight"] = mat(cfg.mlp_hidden, d)
+            else:
+                out[p + f"mlp.{b}.proj_in.bias"] = vec(cfg.mlp_hidden)
+                out[p + f"mlp.{b}.proj_out.bias"] = vec(d)
             out[p + f"mlp.{b}.proj_in.weight"] = mat(cfg.mlp_hidden, d)
             out[p + f"mlp.{b}.proj_out.weight"] = mat(d, cfg.mlp_hidden)
             for l in ("attn", "mlp"):

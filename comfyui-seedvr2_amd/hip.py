@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libseedvr2_hip.so")
 
-EPI_BIAS, EPI_GATE_RES, EPI_SWIGLU, EPI_PIXSHUF3D = 0, 1, 2, 3
+EPI_BIAS, EPI_GATE_RES, EPI_SWIGLU, EPI_PIXSHUF3D, EPI_GELU = 0, 1, 2, 3, 4
 
 
 class HipError(RuntimeError):

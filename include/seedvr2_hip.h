@@ -56,11 +56,12 @@ int svr2_device_check(int dev);
  *                        [ref: modulation.py:112-116, nablocks/mmsr_block.py:112-113,125-126]
  *   SVR2_EPI_SWIGLU     W rows interleaved [8 gate | 8 in] per 16; C[M,N/2] = silu(g) * i
  *                        [ref: models/dit_3b/mlp.py:60-61]
+ *   SVR2_EPI_GELU       C = gelu_tanh(acc + bias)          7B MLP [ref: models/dit_7b/mlp.py:28-43]
  *   SVR2_EPI_PIXSHUF3D  Upsample3D: 1x1x1 conv C->C*r then 'b (x y z c) f h w -> b c (f z)(h x)(w y)',
  *                        optional remove_head [ref: attn_video_vae.py:135-143,152-153;
  *                        causal_inflation_lib.py:412-419]; A rows are (f,h,w) raster, C is [F',2H,2W,C].
  */
-enum { SVR2_EPI_BIAS = 0, SVR2_EPI_GATE_RES = 1, SVR2_EPI_SWIGLU = 2, SVR2_EPI_PIXSHUF3D = 3 };
+enum { SVR2_EPI_BIAS = 0, SVR2_EPI_GATE_RES = 1, SVR2_EPI_SWIGLU = 2, SVR2_EPI_PIXSHUF3D = 3, SVR2_EPI_GELU = 4 };
 
 typedef struct svr2_gemm_desc {
     int64_t M, N, K;

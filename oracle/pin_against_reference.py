@@ -237,6 +237,35 @@ def main():
                              "cfg": {"vid_dim": 64, "heads": 2, "head_dim": 32, "num_layers": cfg.num_layers,
                                      "mm_layers": cfg.mm_layers, "mlp_multiple_of": 32}}
 
+    # ------------------------------------------------------------------ G11 the 7B transformer block (RoPE off)
+    from src.models.dit_7b.nablocks.mmsr_block import NaMMSRTransformerBlock as Block7B
+    from src.models.dit_7b.modulation import get_ada_layer as get_ada7
+    from src.models.dit_7b.normalization import get_norm_layer as get_norm7
+    torch.manual_seed(13)
+    cfg7 = odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, num_layers=2, mm_layers=2, mlp_type="normal",
+                          out_norm=False, last_vid_only=False)
+    blk7 = Block7B(vid_dim=64, txt_dim=64, emb_dim=384, heads=2, head_dim=32, expand_ratio=4,
+                   norm=get_norm7("fusedrms"), norm_eps=1e-5, ada=get_ada7("single"), qk_bias=False, qk_rope=False,
+                   qk_norm=get_norm7("fusedrms"), shared_qkv=False, shared_mlp=False, mlp_type="normal",
+                   window=(4, 3, 3), window_method=owin.SHIFTED)
+    with torch.no_grad():
+        for n_, p_ in blk7.named_parameters():
+            if "norm_" in n_:
+                p_.copy_(1 + 0.1 * torch.randn_like(p_))
+    grid7 = (3, 10, 14)
+    vid7, txt7, emb7 = torch.randn(3 * 10 * 14, 64), torch.randn(58, 64), torch.randn(1, 384)
+    with torch.no_grad():
+        v7, t7, _, _ = blk7(vid7.clone(), txt7.clone(), torch.tensor([list(grid7)]), torch.tensor([[58]]), emb7,
+                            Cache(disable=True))
+    p7 = {f"blocks.0.{k}": v.detach() for k, v in blk7.state_dict().items()}
+    v7m, t7m, _ = odit.block(p7, cfg7, 0, vid7, txt7, emb7[0], grid7, torch.float32, "none", method=owin.SHIFTED)
+    check("G11 7B transformer block vid", v7m, v7, 2e-5)
+    check("G11 7B transformer block txt", t7m, t7, 2e-5)
+    for k, v in p7.items():
+        tensors[f"G11.p.{k}"] = v.contiguous()
+    tensors.update({"G11.vid": vid7, "G11.txt": txt7, "G11.emb": emb7, "G11.vid_out": v7, "G11.txt_out": t7})
+    meta["G11"] = {"grid": list(grid7), "method": owin.SHIFTED}
+
     # ------------------------------------------------------------------ G9 one-step Euler endpoint
     from src.common.diffusion.schedules.lerp import LinearInterpolationSchedule
     from src.common.diffusion.samplers.euler import EulerSampler

@@ -43,6 +43,11 @@ class DiTConfig:
     patch: Tuple[int, int, int] = (1, 2, 2)
     window: Tuple[int, int, int] = (4, 3, 3)
     mlp_multiple_of: int = 256
+    # 7B deltas (dit_7b/nadit.py:39-190, configs_7b/main.yaml): GELU MLP with biases, no vid_out_norm/ada,
+    # no vid-only last layer, all layers with separate vid/txt weights (mm_layers = num_layers)
+    mlp_type: str = "swiglu"       # "swiglu" (3B, mlp.py:46-62) | "normal" (7B, dit_7b/mlp.py:28-43)
+    out_norm: bool = True          # vid_out_norm + vid_out_ada (3B only, nadit.py:167-179)
+    last_vid_only: bool = True     # 3B: last layer's mlp/ada are vid_only (mmsr_block.py:73-82)
 
     @property
     def emb_dim(self) -> int:
@@ -50,6 +55,8 @@ class DiTConfig:
 
     @property
     def mlp_hidden(self) -> int:
+        if self.mlp_type == "normal":
+            return self.vid_dim * self.expand_ratio  # dit_7b/mlp.py:34
         # mlp.py:54-55
         hid = int(2 * self.vid_dim * self.expand_ratio / 3)
         m = self.mlp_multiple_of
@@ -65,6 +72,8 @@ class DiTConfig:
 
 
 CFG_3B = DiTConfig()
+CFG_7B = DiTConfig(vid_dim=3072, heads=24, num_layers=36, mm_layers=36, mlp_type="normal", out_norm=False,
+                   last_vid_only=False)
 
 
 def param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:
@@ -82,14 +91,13 @@ def param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:
         "emb_in.proj_hid.bias": (d,),
         "emb_in.proj_out.weight": (cfg.emb_dim, d),
         "emb_in.proj_out.bias": (cfg.emb_dim,),
-        "vid_out_norm.weight": (d,),
-        "vid_out_ada.out_shift": (d,),
-        "vid_out_ada.out_scale": (d,),
         "vid_out.proj.weight": (cfg.vid_out_channels * pt * ph * pw, d),
         "vid_out.proj.bias": (cfg.vid_out_channels * pt * ph * pw,),
     }
+    if cfg.out_norm:
+        s.update({"vid_out_norm.weight": (d,), "vid_out_ada.out_shift": (d,), "vid_out_ada.out_scale": (d,)})
     for i in range(cfg.num_layers):
-        last = i == cfg.num_layers - 1
+        last = cfg.last_vid_only and i == cfg.num_layers - 1
         branches = ("all",) if cfg.shared(i) else ("vid", "txt")
         p = f"blocks.{i}."
         for b in branches:
@@ -100,9 +108,15 @@ def param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:
             s[p + f"attn.norm_k.{b}.weight"] = (hd,)
             if last and b == "txt":
                 continue  # vid_only modules have no txt copy (mm.py:52-57)
-            s[p + f"mlp.{b}.proj_in_gate.weight"] = (cfg.mlp_hidden, d)
-            s[p + f"mlp.{b}.proj_in.weight"] = (cfg.mlp_hidden, d)
-            s[p + f"mlp.{b}.proj_out.weight"] = (d, cfg.mlp_hidden)
+            if cfg.mlp_type == "swiglu":
+                s[p + f"mlp.{b}.proj_in_gate.weight"] = (cfg.mlp_hidden, d)
+                s[p + f"mlp.{b}.proj_in.weight"] = (cfg.mlp_hidden, d)
+                s[p + f"mlp.{b}.proj_out.weight"] = (d, cfg.mlp_hidden)
+            else:
+                s[p + f"mlp.{b}.proj_in.weight"] = (cfg.mlp_hidden, d)
+                s[p + f"mlp.{b}.proj_in.bias"] = (cfg.mlp_hidden,)
+                s[p + f"mlp.{b}.proj_out.weight"] = (d, cfg.mlp_hidden)
+                s[p + f"mlp.{b}.proj_out.bias"] = (d,)
             for l in ("attn", "mlp"):
                 for g in ("shift", "scale", "gate"):
                     s[p + f"ada.{b}.{l}_{g}"] = (d,)
@@ -209,9 +223,12 @@ def window_attention(q, k, v, tq, tk, tv, grid, boxes, txt_len, cfg: DiTConfig, 
             tqw = _rope.rotate_interleaved(tq.float(), at[:, None, :]).to(dtype)
             tkw = _rope.rotate_interleaved(tk.float(), at[:, None, :]).to(dtype)
         elif rope_mode == "7b":
-            av = _rope.window_angles_7b(shp, D)
-            qw = _rope.rotate_interleaved(qw.float(), av[:, None, :]).to(dtype)
-            kw = _rope.rotate_interleaved(kw.float(), av[:, None, :]).to(dtype)
+            # dit_7b/rope.py:88-89: freqs are cast to q's dtype before apply_rotary_emb, so under bf16 the
+            # ANGLES (and their cos/sin) are bf16-quantised; the rotation itself runs on q.float()
+            av = _rope.window_angles_7b(shp, D).to(dtype)
+            cs, sn = av.cos(), av.sin()
+            qw = _rope.rotate_interleaved_cs(qw.float(), cs[:, None, :], sn[:, None, :]).to(dtype)
+            kw = _rope.rotate_interleaved_cs(kw.float(), cs[:, None, :], sn[:, None, :]).to(dtype)
         # sequence = [window video tokens ; all text tokens] (na.py:386-393)
         qs = torch.cat((qw, tqw)).permute(1, 0, 2)  # [H, S, D]
         ks = torch.cat((kw, tkw)).permute(1, 0, 2)
@@ -234,7 +251,7 @@ def block(p, cfg: DiTConfig, i: int, x, y, emb, grid, dtype=torch.float32, rope_
     H, D = cfg.heads, cfg.head_dim
     W_ = lambda k: p[k].to(dtype)
     Lt = y.shape[0]
-    last = i == cfg.num_layers - 1
+    last = cfg.last_vid_only and i == cfg.num_layers - 1
     bv, bt = ("all", "all") if cfg.shared(i) else ("vid", "txt")
     pre = f"blocks.{i}."
     boxes = _win.windows_for(method or cfg.window_method(i), grid, cfg.window)
@@ -265,14 +282,18 @@ def block(p, cfg: DiTConfig, i: int, x, y, emb, grid, dtype=torch.float32, rope_
     x1 = ada(ov, bv, "attn", "out") + x
     y1 = (ot if last else ada(ot, bt, "attn", "out")) + y
     # --- mlp half (mmsr_block.py:115-126)
-    xm = ada(rms_norm(x1, cfg.norm_eps), bv, "mlp", "in")
-    xm = F.linear(F.silu(F.linear(xm, W_(pre + f"mlp.{bv}.proj_in_gate.weight"))) *
-                  F.linear(xm, W_(pre + f"mlp.{bv}.proj_in.weight")), W_(pre + f"mlp.{bv}.proj_out.weight"))
+    def mlp(h, b):
+        if cfg.mlp_type == "swiglu":  # mlp.py:60-61
+            return F.linear(F.silu(F.linear(h, W_(pre + f"mlp.{b}.proj_in_gate.weight"))) *
+                            F.linear(h, W_(pre + f"mlp.{b}.proj_in.weight")), W_(pre + f"mlp.{b}.proj_out.weight"))
+        h = F.linear(h, W_(pre + f"mlp.{b}.proj_in.weight"), W_(pre + f"mlp.{b}.proj_in.bias"))  # dit_7b/mlp.py:39-43
+        return F.linear(F.gelu(h, approximate="tanh"), W_(pre + f"mlp.{b}.proj_out.weight"),
+                        W_(pre + f"mlp.{b}.proj_out.bias"))
+
+    xm = mlp(ada(rms_norm(x1, cfg.norm_eps), bv, "mlp", "in"), bv)
     xo = ada(xm, bv, "mlp", "out") + x1
     if not last:
-        ym = ada(rms_norm(y1, cfg.norm_eps), bt, "mlp", "in")
-        ym = F.linear(F.silu(F.linear(ym, W_(pre + f"mlp.{bt}.proj_in_gate.weight"))) *
-                      F.linear(ym, W_(pre + f"mlp.{bt}.proj_in.weight")), W_(pre + f"mlp.{bt}.proj_out.weight"))
+        ym = mlp(ada(rms_norm(y1, cfg.norm_eps), bt, "mlp", "in"), bt)
         yo = ada(ym, bt, "mlp", "out") + y1
     else:
         yo = y1 + y1  # mmsr_block.py:126 with vid_only pass-through; value unused downstream
@@ -305,9 +326,10 @@ def forward(p: Dict[str, torch.Tensor], cfg: DiTConfig, vid: torch.Tensor, txt: 
 
     # nadit.py:234-244 - vid_out_norm (affine) then vid_out_ada: reuses the cached attn-layer
     # emb slice (cache key 'emb_repeat_0_vid', modulation.py:79-86) + its own out_shift/out_scale.
-    x = rms_norm(x, cfg.norm_eps, W_("vid_out_norm.weight"))
-    sh, sc, _ = ada_slices(emb, 0)
-    x = x * (sc + W_("vid_out_ada.out_scale")) + (sh + W_("vid_out_ada.out_shift"))
+    if cfg.out_norm:  # 7B has neither (dit_7b/nadit.py:137-141, :188)
+        x = rms_norm(x, cfg.norm_eps, W_("vid_out_norm.weight"))
+        sh, sc, _ = ada_slices(emb, 0)
+        x = x * (sc + W_("vid_out_ada.out_scale")) + (sh + W_("vid_out_ada.out_shift"))
     x = F.linear(x, W_("vid_out.proj.weight"), W_("vid_out.proj.bias"))
     return patch_out(x, grid, cfg.patch, cfg.vid_out_channels)
 

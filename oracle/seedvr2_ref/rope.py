@@ -43,6 +43,15 @@ def rotate_interleaved(x: torch.Tensor, angles: torch.Tensor) -> torch.Tensor:
     return torch.cat((xm * angles.cos() + rh * angles.sin(), xr), dim=-1)
 
 
+def rotate_interleaved_cs(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """Same rotation with precomputed (possibly low-precision) cos/sin tables."""
+    rot = cos.shape[-1]
+    xm, xr = x[..., :rot], x[..., rot:]
+    x1, x2 = xm[..., 0::2], xm[..., 1::2]
+    rh = torch.stack((-x2, x1), dim=-1).flatten(-2)
+    return torch.cat((xm * cos + rh * sin, xr), dim=-1)
+
+
 def mm_window_angles_3b(shape_thw, txt_len: int, head_dim: int = 128):
     """Angles for one window of extent (f,h,w) and for the text tokens (3B mmrope3d).
 

@@ -118,6 +118,19 @@ def test_oracle_transformer_block_golden(gold, tag):
         assert (yo - t[f"G8.{tag}.txt_out"]).abs().max() < 2e-5
 
 
+def test_oracle_7b_transformer_block_golden(gold):
+    """NaDiT-7B block (GELU MLP with biases, separate vid/txt weights everywhere, no vid-only last layer):
+    reference modules of dit_7b run as-is (RoPE off) vs the oracle."""
+    from seedvr2_ref import dit as odit
+    meta, t = gold
+    cfg = odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, num_layers=2, mm_layers=2, mlp_type="normal",
+                         out_norm=False, last_vid_only=False)
+    p = {k[len("G11.p."):]: v for k, v in t.items() if k.startswith("G11.p.")}
+    xo, yo, _ = odit.block(p, cfg, 0, t["G11.vid"], t["G11.txt"], t["G11.emb"][0], tuple(meta["G11"]["grid"]),
+                           torch.float32, "none", method=meta["G11"]["method"])
+    assert (xo - t["G11.vid_out"]).abs().max() < 2e-5 and (yo - t["G11.txt_out"]).abs().max() < 2e-5
+
+
 def test_oracle_rope_properties():
     """RoPE arithmetic is 'parity unpinned' (rotary_embedding_torch absent): check its invariants."""
     from seedvr2_ref import rope

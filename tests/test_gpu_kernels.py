@@ -249,3 +249,35 @@ def test_dit_one_step_vs_oracle(pkg, gpu, grid_thw):
     assert torch.isfinite(got).all()
     assert e_hip <= 2.0 * e_b16 + 1e-3, (e_hip, e_b16)
     assert_close(got, ref32, "dit one_step", rtol=5e-2, atol_rel=5e-2)
+
+
+def test_gemm_gelu(pkg, gpu):
+    hip = pkg.hip
+    M, N, K = 200, 384, 128
+    a, w, b = rnd(M, K, seed=95), rnd(N, K, seed=96, scale=0.2), rnd(N, seed=97)
+    out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, epilogue=hip.EPI_GELU, bias=b.to(gpu))
+    assert_close(out, F.gelu(a @ w.T + b, approximate="tanh"), "gemm gelu")
+
+
+@pytest.mark.parametrize("grid_thw", [(2, 16, 24), (3, 20, 36)])
+def test_dit_7b_variant_vs_oracle(pkg, gpu, grid_thw):
+    """NaDiT-7B deltas: GELU MLP with biases, separate vid/txt weights in every layer, video-only 'pixel'
+    rope with bf16-quantised angles, no output norm / vid-only last layer."""
+    from seedvr2_ref import dit as odit
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=2, mm_layers=2, txt_in_dim=64, mlp_type="normal",
+              out_norm=False, last_vid_only=False)
+    ocfg = odit.DiTConfig(**kw)
+    p = {k: bf(v) for k, v in odit.synthetic_params(ocfg, 5).items()}
+    model = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(rope_mode=2, **kw), p, gpu)
+    T, H, W = grid_thw
+    noise, latent, txt = rnd(T, H, W, 16, seed=90), rnd(T, H, W, 16, seed=91), rnd(58, 64, seed=92)
+    got = model.one_step(dev_bf16(noise, gpu), dev_bf16(latent, gpu), txt.to(gpu)).float().cpu()
+    # the reference quantises the rope angles to the activations' dtype: compare against the bf16-angle oracle
+    ref16 = odit.one_step_sr(p, ocfg, latent, noise, txt, torch.bfloat16, rope_mode="7b").float()
+    ref32 = odit.one_step_sr(p, ocfg, latent, noise, txt, torch.float32, rope_mode="7b")
+    rms = ref16.pow(2).mean().sqrt()
+    e_hip = (got - ref16).pow(2).mean().sqrt() / rms
+    e_32 = (ref32 - ref16).pow(2).mean().sqrt() / rms
+    print(f"DiT-7B {grid_thw}: rel-rms hip-vs-bf16oracle={e_hip:.3e}  fp32oracle-vs-bf16oracle={e_32:.3e}")
+    assert torch.isfinite(got).all()
+    assert e_hip < 3e-2
