@@ -202,6 +202,8 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
         stage = (G::STAGES == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            // (hipcc's own interleave of these reads and MFMAs measured 7 % faster than pinning
+            //  "16 reads, then 32 MFMAs" with sched_group_barrier)
             bf16x8 af[4], bfr[4];
             const int chunk = ((fq + 4 * ks) ^ swz) << 4;
 #pragma unroll

@@ -43,9 +43,8 @@ def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pi
         if dpath is None or vpath is None:
             raise RuntimeError(f"model files not found: {dit_cfg['model']} / {vae_cfg['model']} "
                                "(no network download on this path; place them under models/SEEDVR2)")
-        if _weights.config_for(dit_cfg["model"]) != "3b":
-            raise NotImplementedError("NaDiT-7B deltas are not wired into the HIP runner yet")
-        dit = _dit.NaDiTHip(_dit.CFG_3B, _weights.load_state_dict(dpath), dev)
+        cfg = _dit.CFG_7B if _weights.config_for(dit_cfg["model"]) == "7b" else _dit.CFG_3B
+        dit = _dit.NaDiTHip(cfg, _weights.load_state_dict(dpath), dev)
         vae = _vae.VideoVAEHip(_vae.VAEConfig(), _weights.load_state_dict(vpath), dev)
         _PIPELINES[key] = _pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev)
     return _PIPELINES[key]
