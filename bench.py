@@ -181,12 +181,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    backend = os.environ.get("SVR2_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 control flow on one GPU
+    if backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
 
     pkg = ge.load_package()
     hip = pkg.hip
@@ -225,13 +231,15 @@ def main():
                 hip.blend_overlap(prev_tail[0], sample[:overlap].contiguous(), w_prev, prev_tail[0])
             if world > 1:                 # segment boundary: head frames go to the left neighbour
                 ops = []
-                recv = torch.empty_like(sample[:overlap])
+                stage = (lambda t: t.cpu()) if backend == "gloo" else (lambda t: t)  # gloo p2p needs host tensors
+                recv = stage(torch.empty_like(sample[:overlap]))
                 if rank > 0:
-                    ops.append(dist.P2POp(dist.isend, sample[:overlap].contiguous(), rank - 1))
+                    ops.append(dist.P2POp(dist.isend, stage(sample[:overlap].contiguous()), rank - 1))
                 if rank < world - 1:
                     ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
                 for r in dist.batch_isend_irecv(ops):
                     r.wait()
+                recv = recv.to(dev)
                 if rank < world - 1:
                     tail = sample[-overlap:].contiguous()
                     hip.blend_overlap(tail, recv, w_prev, tail)
@@ -240,6 +248,7 @@ def main():
         return out
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -259,7 +268,7 @@ def main():
     dt = time.perf_counter() - t0
     ktimer.enabled = False
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     peak_gb = torch.cuda.max_memory_reserved() / 1e9

@@ -38,6 +38,7 @@ enum AMode { A_DENSE = 0, A_CONV = 1 };
 struct ConvGeom {
     const bf16* carry;
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
+    int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
 };
 
 struct KArgs {
@@ -70,6 +71,22 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
     tn = rem / rows;
 }
 
+// Output row (pixel) index of row `row` of M-tile `tm`.  Conv tiles are 2-D pixel patches (BM/16 rows x 16
+// columns of one frame) so that a workgroup's nine spatial taps, and the ~64 workgroups resident on one
+// XCD, re-read a compact halo from L2 instead of three full image rows per frame (rocprof FETCH_SIZE showed
+// 12x the input crossing the L2 with row-major 128-pixel tiles).
+template <int AMODE, int BM>
+__device__ __forceinline__ int tile_row_to_m(const KArgs& a, int tm, int row) {
+    if (AMODE == A_CONV && a.cg.patch) {
+        const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
+        const int t = tm / per_frame, rem = tm - t * per_frame;
+        const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
+        const int y = ty * (BM / 16) + (row >> 4), x = tx * 16 + (row & 15);
+        return (t * a.cg.Ho + y) * a.cg.Wo + x;
+    }
+    return tm * BM + row;
+}
+
 template <int AMODE, int EPI, int BM>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
     using G = Geo<BM>;
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + lrow;
         const int chunk = lpos ^ ((r >> 1) & 7);
-        const int m = m0 + r;
+        const int m = tile_row_to_m<AMODE, BM>(a, tm, r);
         if (AMODE == A_DENSE) {
             long long src = m;
             if (a.a_rows) src = a.a_rows[m < a.M ? m : a.M - 1];
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
         // columns [16p, 16p+8) = gate, [16p+8, 16p+16) = in  ->  output columns [8p, 8p+8)
         for (int c = tid; c < BM * 8; c += NTHREADS) {
             const int row = c >> 3, p = c & 7;
-            const int m = m0 + row, ncol = (n0 >> 1) + p * 8;
+            const int m = tile_row_to_m<AMODE, BM>(a, tm, row), ncol = (n0 >> 1) + p * 8;
             if (m >= a.M || (n0 + p * 16) >= a.N) continue;
             const float* g = tile + row * BN + p * 16;
             bf16x8 o;
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
 
     for (int c = tid; c < BM * 16; c += NTHREADS) {
         const int row = c >> 4, cc = c & 15;
-        const int m = m0 + row, n = n0 + cc * 8;
+        const int m = tile_row_to_m<AMODE, BM>(a, tm, row), n = n0 + cc * 8;
         if (m >= a.M || n >= a.N) continue;
         const float* src = tile + row * BN + cc * 8;
         float v[8];
@@ -318,12 +335,16 @@ int launch_bm(KArgs a, hipStream_t s) {
     }
     a.nbm = (a.M + BM - 1) / BM;
     a.nbn = (a.N + BN - 1) / BN;
+    if (AMODE == A_CONV) {
+        a.cg.patch = (a.cg.Ho % (BM / 16) == 0 && a.cg.Wo % 16 == 0 && !getenv("SVR2_CONV_LINEAR_TILES")) ? 1 : 0;
+        a.cg.tiles_x = a.cg.Wo / 16;
+        a.cg.tiles_y = a.cg.Ho / (BM / 16);
+    }
     hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, BM>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS_BYTES, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
 
-// Tile choice: 256-row tiles once the grid still fills the chip (>= 2 tiles per CU), else 128-row tiles.
 inline int g_force_bm() {
     static int v = -1;
     if (v < 0) {
@@ -334,9 +355,10 @@ inline int g_force_bm() {
 }
 template <int AMODE, int EPI>
 int launch(const KArgs& a, hipStream_t s) {
-    const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
-    const int force = g_force_bm();
-    const bool big = force ? force == 256 : tiles256 >= 512;
+    // measured on MI355X (profiles/r01_kernel_bench_*.log): two 128-row workgroups per CU beat one 256-row,
+    // 3-stage workgroup by ~5 % on every shape of the path, so 128 is the default; SVR2_GEMM_BM=256 selects
+    // the other geometry for A/B runs.
+    const bool big = g_force_bm() == 256;
     return big ? launch_bm<AMODE, EPI, 256>(a, s) : launch_bm<AMODE, EPI, 128>(a, s);
 }
 

@@ -93,6 +93,11 @@ CONV_CASES = [
     (4, 12, 20, 64, 64, (3, 3, 3), (2, 2, 2), 1, (0, 1, 0, 1), True, False),    # ... later chunk with 1 carried frame
     (2, 9, 7, 128, 256, (1, 1, 1), (1, 1, 1), 0, (0, 0, 0, 0), False, False),   # 1x1x1 shortcut
     (1, 16, 16, 64, 16, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), False, False),   # small Cout
+    # Ho % 8 == 0 and Wo % 16 == 0: the 2-D patch tiling of the output is active
+    (3, 16, 32, 64, 128, (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), True, True),
+    (5, 16, 32, 64, 64, (3, 3, 3), (2, 2, 2), 2, (0, 1, 0, 1), False, False),
+    (2, 24, 48, 128, 64, (1, 3, 3), (1, 1, 1), 0, (1, 1, 1, 1), False, True),
+    (2, 8, 16, 64, 200, (1, 1, 1), (1, 1, 1), 0, (0, 0, 0, 0), False, False),
 ]
 
 
