@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg3": (21, 720, 1280, 2160, 4, "SeedVR2-3B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[2])"),
     "cfg2": (9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8(+1 pad)-frame 540p->1080p (BASELINE configs[1])"),
     "cfg1": (1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
+    "cfg2o": (9, 540, 960, 1080, 4, "rehearsal: cfg2 shape with temporal_overlap 4 (exercises the neighbour exchange)"),
     "cfg4": (21, 720, 1280, 2160, 4, "SeedVR2-7B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[3])"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
