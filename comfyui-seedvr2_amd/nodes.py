@@ -45,7 +45,7 @@ def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pi
                                "(no network download on this path; place them under models/SEEDVR2)")
         cfg = _dit.CFG_7B if _weights.config_for(dit_cfg["model"]) == "7b" else _dit.CFG_3B
         dit = _dit.NaDiTHip(cfg, _weights.load_state_dict(dpath), dev)
-        vae = _vae.VideoVAEHip(_vae.VAEConfig(), _weights.load_state_dict(vpath), dev)
+        vae = _vae.VideoVAEHip(_vae.VAEConfig(), _weights.normalize_vae_state_dict(_weights.load_state_dict(vpath)), dev)
         _PIPELINES[key] = _pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev)
     return _PIPELINES[key]
 

@@ -35,3 +35,29 @@ def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
 def config_for(dit_name: str):
     """configs_3b vs configs_7b by file name [ref: src/core/model_configuration.py:715-717]."""
     return "7b" if "7b" in dit_name else "3b"
+
+
+_DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def normalize_vae_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Checkpoint key layout -> the layout VideoVAEHip consumes (the reference's module tree):
+      * old diffusers attention names (query/key/value/proj_attn) -> to_q/to_k/to_v/to_out.0, the
+        conversion diffusers applies in `_convert_deprecated_attention_blocks`, which the reference calls
+        before loading [ref: src/models/video_vae_v3/modules/attn_video_vae.py:1639-1649];
+      * 1x1 conv-style attention projections [C,C,1,1] -> [C,C];
+      * conv weights must already be 5-D: the shipped config uses inflation_mode 'pad', for which the
+        reference's 2-D -> 3-D inflation asserts [ref: causal_inflation_lib.py:447,316-335]."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if "attentions" in parts and len(parts) >= 2 and parts[-2] in _DEPRECATED_ATTN:
+            parts[-2] = _DEPRECATED_ATTN[parts[-2]]
+            k = ".".join(parts)
+        if "attentions" in parts and k.endswith(".weight") and v.dim() == 4 and v.shape[2:] == (1, 1):
+            v = v[:, :, 0, 0]
+        if k.endswith(".weight") and v.dim() == 4 and "attentions" not in parts:
+            raise ValueError(f"{k}: 2-D conv weight in a causal 3-D VAE checkpoint (inflation is not defined for "
+                             "inflation_mode 'pad')")
+        out[k] = v
+    return out

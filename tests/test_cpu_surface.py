@@ -58,3 +58,30 @@ def test_runner_condition_matches_reference_semantics(pkg):
     assert cond.shape == (2, 3, 4, 17) and torch.equal(cond[..., :16], lat) and (cond[..., 16] == 1).all()
     with pytest.raises(NotImplementedError):
         pkg.infer.VideoDiffusionInfer(vae_tiling_enabled=True)
+
+
+def test_vae_checkpoint_key_normalisation(pkg):
+    """Deprecated diffusers attention names are converted like the reference does before loading; the
+    synthetic state dict (reference key layout) round-trips; 2-D conv weights are rejected."""
+    W = pkg.weights
+    sd = {"decoder.mid_block.attentions.0.query.weight": torch.zeros(8, 8, 1, 1),
+          "decoder.mid_block.attentions.0.proj_attn.bias": torch.zeros(8),
+          "decoder.conv_in.weight": torch.zeros(8, 4, 3, 3, 3)}
+    out = W.normalize_vae_state_dict(sd)
+    assert set(out) == {"decoder.mid_block.attentions.0.to_q.weight", "decoder.mid_block.attentions.0.to_out.0.bias",
+                        "decoder.conv_in.weight"}
+    assert out["decoder.mid_block.attentions.0.to_q.weight"].shape == (8, 8)
+    with pytest.raises(ValueError):
+        W.normalize_vae_state_dict({"encoder.conv_in.weight": torch.zeros(8, 3, 3, 3)})
+    from seedvr2_ref import vae as ovae
+    ch = (32, 32, 64, 64)
+    keys = set(ovae.param_shapes(ovae.VAEConfig(block_out_channels=ch)))
+    syn = pkg.vae.synthetic_state_dict(pkg.vae.VAEConfig(block_out_channels=ch), "cpu", dtype=torch.float32)
+    assert set(syn) == keys == set(W.normalize_vae_state_dict(syn))
+    from seedvr2_ref import dit as odit
+    assert set(pkg.dit.synthetic_state_dict(pkg.dit.DiTConfig(vid_dim=64, heads=2, head_dim=32, txt_in_dim=32, num_layers=12, mlp_multiple_of=32), "cpu")) == \
+        set(odit.param_shapes(odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, txt_in_dim=32, num_layers=12, mlp_multiple_of=32)))
+    assert set(pkg.dit.synthetic_state_dict(pkg.dit.DiTConfig(vid_dim=64, heads=2, head_dim=32, txt_in_dim=32, num_layers=2, mm_layers=2,
+                                                               mlp_type="normal", out_norm=False, last_vid_only=False), "cpu")) == \
+        set(odit.param_shapes(odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, txt_in_dim=32, num_layers=2, mm_layers=2,
+                                             mlp_type="normal", out_norm=False, last_vid_only=False)))
