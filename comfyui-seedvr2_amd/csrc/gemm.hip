@@ -235,6 +235,9 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        // LLVM's MFMA/DS interleave strategy for this scheduling region: measured +1.3 % (dense GEMM) to +5 %
+        // (512-channel conv) over the default schedule; s_setprio around the MFMA cluster measured 0 %.
+        __builtin_amdgcn_iglp_opt(1);
     }
 
     // ---- epilogue through an fp32 LDS tile [128][128]

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseedvr2_hip.so")
+LIB_PATH = os.environ.get("SVR2_LIB") or os.path.join(_HERE, "libseedvr2_hip.so")  # SVR2_LIB: A/B builds
 
 EPI_BIAS, EPI_GATE_RES, EPI_SWIGLU, EPI_PIXSHUF3D, EPI_GELU = 0, 1, 2, 3, 4
 
