@@ -273,6 +273,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     peak_gb = torch.cuda.max_memory_reserved() / 1e9
+    log(f"[rank {rank}] peak reserved {peak_gb:.1f} GB, peak allocated {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
 
     if rank == 0:
         nl, kt, kf = ktimer.summary()

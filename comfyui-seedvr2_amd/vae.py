@@ -38,14 +38,20 @@ class VAEConfig:
     eps: float = 1e-6
     scaling_factor: float = 0.9152
     # temporal slicing [ref: configs_3b/main.yaml:53-55; core/model_configuration.py:1237-1248]
-    encode_split: int = 4   # input frames per slice after the first (first slice = 1 + encode_split)
-    decode_split: int = 1   # latent frames per slice after the first (first slice = 1 + decode_split)
+    # The reference's first slice is 1 + split frames; with the carried conv state any slicing gives the same
+    # result (oracle/pin_against_reference.py G10, tests), so the first slice here is frame 0 alone: the
+    # full-resolution working set is then 4 frames instead of 5.
+    encode_split: int = 4   # input frames per slice after the first
+    decode_split: int = 1   # latent frames per slice after the first
+    encode_first: int = 1   # input frames in the first slice (reference: 1 + encode_split)
+    decode_first: int = 1   # latent frames in the first slice (reference: 1 + decode_split)
 
 
 class _State:
     def __init__(self):
         self.mem: Dict[str, torch.Tensor] = {}
         self.active = False
+        self.last = False   # final chunk: nothing to carry
 
 
 class VideoVAEHip:
@@ -93,12 +99,6 @@ class VideoVAEHip:
             carry, npad = st.mem[name], keep
         else:
             carry, npad = None, 2 * ((kt - 1) // 2)  # first chunk: replicate frame 0  [ref: causal_inflation_lib.py:422-437]
-        if keep > 0:
-            if x.shape[0] >= keep:
-                new_mem = x[x.shape[0] - keep:].clone()
-            else:
-                head = carry if carry is not None else x[:1].expand(npad, -1, -1, -1)
-                new_mem = torch.cat((head, x), dim=0)[-keep:].contiguous()
         if "kpad" in c:
             col = hip.im2col3d(x, c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry, kpad=c["kpad"])
             to, ho, wo = hip.conv_out_size(x.shape[0], x.shape[1], x.shape[2], c["k"], stride, npad, pad_hw)
@@ -108,8 +108,18 @@ class VideoVAEHip:
         else:
             y = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
                            bias=c["bias"], resid=resid)
-        if keep > 0:
-            st.mem[name] = new_mem
+        if keep > 0 and not st.last:
+            # carry the last `keep` input frames to the next chunk  [ref: causal_inflation_lib.py:266-278].  The old
+            # carry is released first (stream-ordered reuse: the conv that reads it is already enqueued).
+            if x.shape[0] >= keep:
+                carry = None
+                st.mem[name] = None
+                st.mem[name] = x[x.shape[0] - keep:].clone()
+            else:
+                head = carry if carry is not None else x[:1].expand(npad, -1, -1, -1)
+                st.mem[name] = torch.cat((head, x), dim=0)[-keep:].clone()
+        elif keep > 0:
+            st.mem.pop(name, None)
         return y
 
     def _norm(self, name: str, x: torch.Tensor, silu: bool = True) -> torch.Tensor:
@@ -189,10 +199,13 @@ class VideoVAEHip:
             raise hip.HipError(f"encode: expected [4n+1, 8a, 8b, {cfg.in_channels}], got {tuple(x.shape)}")
         st = _State()
         split = cfg.encode_split
+        if split % 4 or (cfg.encode_first - 1) % 4:
+            raise hip.HipError("encode slices must keep the x4 temporal stride aligned (first = 4a+1, split = 4b)")
         outs = []
         a = 0
         while a < T:
-            b = min(T, a + (1 + split if a == 0 else split)) if (T - 1) > split else T
+            b = min(T, a + (cfg.encode_first if a == 0 else split))
+            st.last = b >= T
             outs.append(self._encoder(x[a:b].contiguous(), st)[..., : cfg.latent_channels])
             st.active = True
             a = b
@@ -212,7 +225,8 @@ class VideoVAEHip:
         outs = []
         a = 0
         while a < Tl:
-            b = min(Tl, a + (1 + split if a == 0 else split)) if (Tl - 1) > split else Tl
+            b = min(Tl, a + (cfg.decode_first if a == 0 else split))
+            st.last = b >= Tl
             outs.append(self._decoder(z[a:b].contiguous(), st))
             st.active = True
             a = b

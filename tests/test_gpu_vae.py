@@ -81,6 +81,9 @@ def test_vae_encode_vs_oracle(pkg, gpu):
     print(f"VAE encode: rel-rms err hip={e_hip:.3e} bf16-oracle={e_b16:.3e}")
     assert got.shape == ref32.shape == (3, 4, 6, 16)
     assert e_hip <= 2.0 * e_b16 + 2e-3
+    model.cfg.encode_first = 5   # the reference's schedule
+    assert _rel(model.encode(dev_bf16(x, gpu)).float().cpu(), got) < 5e-3
+    model.cfg.encode_first = 1
 
 
 def test_vae_decode_vs_oracle_and_chunking(pkg, gpu):
@@ -93,11 +96,14 @@ def test_vae_decode_vs_oracle_and_chunking(pkg, gpu):
     print(f"VAE decode: rel-rms err hip={e_hip:.3e} bf16-oracle={e_b16:.3e}")
     assert got.shape == ref32.shape == (9, 32, 48, 3)
     assert e_hip <= 2.0 * e_b16 + 2e-3
-    # chunk schedule is only a memory schedule: a different split gives (nearly) the same pixels
-    model.cfg.decode_split = 8
+    # chunk schedule is only a memory schedule: the reference's slicing (first = 2 latent frames) and an
+    # unsliced run give (nearly) the same pixels
+    model.cfg.decode_first = 2
+    ref_sched = model.decode(dev_bf16(z, gpu)).float().cpu()
+    model.cfg.decode_first, model.cfg.decode_split = 99, 99
     whole = model.decode(dev_bf16(z, gpu)).float().cpu()
-    model.cfg.decode_split = 1
-    assert _rel(whole, got) < 5e-3
+    model.cfg.decode_first, model.cfg.decode_split = 1, 1
+    assert _rel(whole, got) < 5e-3 and _rel(ref_sched, got) < 5e-3
 
 
 def test_pipeline_end_to_end_psnr(pkg, gpu):
