@@ -11,6 +11,7 @@
 // zero padding and rows past M read a zero page.  Accumulators leave through an fp32 LDS tile so
 // every epilogue works on 8 consecutive columns and stores 16 bytes per lane, whole 256-byte rows.
 #include "common.h"
+#include "gemm_args.h"
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -31,61 +32,8 @@ template <int BM> struct Geo {
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // >= BM*BN*4 (fp32 epilogue tile)
     static constexpr int NBI = 16 / NW;                     // W DMA instructions per wave per K-tile
 };
-constexpr int GROUP_M = 8;                        // band height (in tiles) of the L2-friendly tile order
 
-enum AMode { A_DENSE = 0, A_CONV = 1 };
-
-struct ConvGeom {
-    const bf16* carry;
-    int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
-    int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
-};
-
-struct KArgs {
-    const bf16* A;
-    const bf16* W;
-    bf16* C;
-    const int32_t* a_rows;
-    const float* bias;
-    const float* gate;
-    const bf16* resid;
-    const bf16* zero;
-    long long lda, ldc, ldr;
-    int M, N, K, nbm, nbn;
-    int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
-    ConvGeom cg;
-};
-
-__device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
-    // XCD-aware remap (bijective form): blocks b and b+8 share an XCD; give every XCD a contiguous
-    // run of the tile order, and order tiles in bands of GROUP_M row-tiles so that the workgroups
-    // resident on one XCD share A row-panels and W column-panels in its L2.
-    const int total = a.nbm * a.nbn;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = total >> 3, r = total & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int per_band = GROUP_M * a.nbn;
-    const int band = lin / per_band, rem = lin - band * per_band;
-    const int rows = min(GROUP_M, a.nbm - band * GROUP_M);
-    tm = band * GROUP_M + rem % rows;
-    tn = rem / rows;
-}
-
-// Output row (pixel) index of row `row` of M-tile `tm`.  Conv tiles are 2-D pixel patches (BM/16 rows x 16
-// columns of one frame) so that a workgroup's nine spatial taps, and the ~64 workgroups resident on one
-// XCD, re-read a compact halo from L2 instead of three full image rows per frame (rocprof FETCH_SIZE showed
-// 12x the input crossing the L2 with row-major 128-pixel tiles).
-template <int AMODE, int BM>
-__device__ __forceinline__ int tile_row_to_m(const KArgs& a, int tm, int row) {
-    if (AMODE == A_CONV && a.cg.patch) {
-        const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
-        const int t = tm / per_frame, rem = tm - t * per_frame;
-        const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
-        const int y = ty * (BM / 16) + (row >> 4), x = tx * 16 + (row & 15);
-        return (t * a.cg.Ho + y) * a.cg.Wo + x;
-    }
-    return tm * BM + row;
-}
+using namespace svr2;
 
 template <int AMODE, int EPI, int BM>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
@@ -361,6 +309,12 @@ int launch(const KArgs& a, hipStream_t s) {
     // measured on MI355X (profiles/r01_kernel_bench_*.log): two 128-row workgroups per CU beat one 256-row,
     // 3-stage workgroup by ~5 % on every shape of the path, so 128 is the default; SVR2_GEMM_BM=256 selects
     // the other geometry for A/B runs.
+    // Large problems go to the second-generation kernel (gemm2.hip: 256-row tiles, 128x64 per wave, BK 32,
+    // 3-deep ring); SVR2_GEMM_V=1 keeps everything on this kernel for A/B runs.
+    static int ver = -1;
+    if (ver < 0) { const char* e = getenv("SVR2_GEMM_V"); ver = e ? atoi(e) : 2; }
+    const long long tiles2 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (((ver == 2 && tiles2 >= 384) || ver == 3) && a.K % 32 == 0) return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
     return big ? launch_bm<AMODE, EPI, 256>(a, s) : launch_bm<AMODE, EPI, 128>(a, s);
 }

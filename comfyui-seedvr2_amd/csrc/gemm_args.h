@@ -1,0 +1,65 @@
+// Kernel-argument structs shared by the two GEMM / implicit-conv kernels (gemm.hip, gemm2.hip).
+#pragma once
+#include "common.h"
+
+namespace svr2 {
+
+enum AMode { A_DENSE = 0, A_CONV = 1 };
+
+struct ConvGeom {
+    const bf16* carry;
+    int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
+    int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
+};
+
+struct KArgs {
+    const bf16* A;
+    const bf16* W;
+    bf16* C;
+    const int32_t* a_rows;
+    const float* bias;
+    const float* gate;
+    const bf16* resid;
+    const bf16* zero;
+    long long lda, ldc, ldr;
+    int M, N, K, nbm, nbn;
+    int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
+    ConvGeom cg;
+};
+
+constexpr int GROUP_M_TILES = 8;  // band height (in tiles) of the L2-friendly tile order
+
+// XCD-aware remap (bijective form): blocks b and b+8 share an XCD; give every XCD a contiguous run of the
+// tile order, and order tiles in bands of GROUP_M_TILES row-tiles so that the workgroups resident on one XCD
+// share A row-panels and W column-panels in its L2.
+__device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
+    const int total = a.nbm * a.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_band = GROUP_M_TILES * a.nbn;
+    const int band = lin / per_band, rem = lin - band * per_band;
+    const int rows = min(GROUP_M_TILES, a.nbm - band * GROUP_M_TILES);
+    tm = band * GROUP_M_TILES + rem % rows;
+    tn = rem / rows;
+}
+
+// Output row (pixel) index of row `row` of M-tile `tm`.  Conv tiles are 2-D pixel patches (BM/16 rows x 16
+// columns of one frame) so that a workgroup's nine spatial taps, and the ~64 workgroups resident on one
+// XCD, re-read a compact halo from L2 instead of three full image rows per frame.
+template <int AMODE, int BM>
+__device__ __forceinline__ int tile_row_to_m(const KArgs& a, int tm, int row) {
+    if (AMODE == A_CONV && a.cg.patch) {
+        const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
+        const int t = tm / per_frame, rem = tm - t * per_frame;
+        const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
+        const int y = ty * (BM / 16) + (row >> 4), x = tx * 16 + (row & 15);
+        return (t * a.cg.Ho + y) * a.cg.Wo + x;
+    }
+    return tm * BM + row;
+}
+
+// implemented in gemm2.hip: 256-row tiles, 128x64 per wave, BK = 32, 3-deep DMA ring
+int gemm2_launch(int amode, int epi, KArgs a, hipStream_t s);
+
+}  // namespace svr2
