@@ -314,7 +314,11 @@ int launch(const KArgs& a, hipStream_t s) {
     static int ver = -1;
     if (ver < 0) { const char* e = getenv("SVR2_GEMM_V"); ver = e ? atoi(e) : 2; }
     const long long tiles2 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-    if (((ver == 2 && tiles2 >= 384) || ver == 3) && a.K % 32 == 0) return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
+    // measured (profiles/r01_*): the 256x256x64 geometry wins by 16-20 % wherever N is a multiple of 256; for
+    // N = 128 the 256x128x32 geometry is +3 % on 128-channel inputs and -18 % on 256-channel inputs.
+    const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.cg.Cin <= 128 && a.N == 128);
+    if (((ver == 2 && tiles2 >= 384 && v2_shape) || ver == 3) && a.K % 32 == 0)
+        return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
     return big ? launch_bm<AMODE, EPI, 256>(a, s) : launch_bm<AMODE, EPI, 128>(a, s);
 }
