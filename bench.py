@@ -283,6 +283,14 @@ def main():
         enc_f, dec_f = _vae_flops(T, ph, pw)
         dit_f = _dit_flops(T, ph, pw, "7b" if args.workload == "cfg4" else "3b")
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
+        traffic = None   # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this workload
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_cfg3.json")
+        if args.workload == "cfg3" and os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    traffic = json.load(fh)["kernels"]["conv3d (A_CONV kernels of gemm.hip + gemm2.hip)"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         result = {
             "metric": "upscaled frames/sec + peak HBM GB, SeedVR2-3B 720p->4K, 1/2/4/8 MI355X",
             "value": new_frames * world * args.steps / dt,
@@ -296,9 +304,11 @@ def main():
                        "lr": [hin, win], "out": [th, tw], "padded": [ph, pw], "parallelism": f"frame-chunk x{world}",
                        "algorithmic_tflop_per_step": {"vae_encode": enc_f / 1e12, "dit_gemm": dit_f / 1e12,
                                                       "vae_decode": dec_f / 1e12}},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_CONV> (implicit-GEMM causal conv3d)",
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM causal conv3d (gemm2_kernel<A_CONV,*,256|128> + gemm_kernel<A_CONV,*,128>)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic_cfg3.json)",
+                         "algorithmic_flop_per_launch": kf / nl if nl else None,
                          "launches": nl, "kernel_time_s": kt, "share_of_step_time": kt / dt if dt > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
         w_ptr[i] = (const char*)(a.W + (long long)(n0 + r) * a.K) + ((lpos ^ ((r >> 1) & 7)) << 4);
     }
     // conv tap state (wave-uniform scalars); K order is ((kt*kh + ky)*kw + kx)*Cin + c
-    int tap_t = 0, tap_y = 0, tap_x = 0, tap_c = 0;
+    int tap_t = 0, tap_y = 0, tap_x = 0, tap_c = 0, tap_blk = 0;
     const long long frame_bytes = (long long)a.cg.Hi * a.cg.Wi * a.cg.Cin * 2;
     auto set_frame = [&]() {  // a_ptr[i] = base of padded frame (ct[i] + tap_t) + rowoff[i]; runs when tap_t changes
 #pragma unroll
@@ -104,22 +104,29 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
                 if (a_ptr[i]) a_ptr[i] += BK * 2;
             }
         } else {
-            const long long toff = (((long long)tap_y * a.cg.Wi + tap_x) * a.cg.Cin + tap_c) * 2;  // scalar
+            const long long toff = (((long long)tap_y * a.cg.Wi + tap_x) * a.cg.Cin + tap_blk + tap_c) * 2;  // scalar
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = ((unsigned)(cy[i] + tap_y) < (unsigned)a.cg.Hi) & ((unsigned)(cx[i] + tap_x) < (unsigned)a.cg.Wi);
                 const char* src = a_ptr[i] + toff;
                 glds16(ok ? src : zsrc, sA + (wave * 4 + i) * 1024);
             }
+            // K order: 64-channel slice innermost, then the kh*kw spatial taps, then the channel slices, then the
+            // temporal taps - the 9 spatial taps of one slice re-read the same 128-byte lines within 9 consecutive
+            // K-steps, so they hit in L2 (tap-major order over all channels thrashed it: 18x the input in FETCH_SIZE)
             tap_c += BK;
-            if (tap_c == a.cg.Cin) {
+            if (tap_c == CONV_SLICE) {
                 tap_c = 0;
                 if (++tap_x == a.cg.kw) {
                     tap_x = 0;
                     if (++tap_y == a.cg.kh) {
                         tap_y = 0;
-                        ++tap_t;
-                        set_frame();
+                        tap_blk += CONV_SLICE;
+                        if (tap_blk == a.cg.Cin) {
+                            tap_blk = 0;
+                            ++tap_t;
+                            set_frame();
+                        }
                     }
                 }
             }

@@ -27,6 +27,7 @@ struct KArgs {
     ConvGeom cg;
 };
 
+constexpr int CONV_SLICE = 64;    // channels per K slice of the conv weight layout [Cout][kt][Cin/64][kh][kw][64]
 constexpr int GROUP_M_TILES = 8;  // band height (in tiles) of the L2-friendly tile order
 
 // XCD-aware remap (bijective form): blocks b and b+8 share an XCD; give every XCD a contiguous run of the

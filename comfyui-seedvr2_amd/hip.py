@@ -141,6 +141,16 @@ def pad_weight(w: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
     return out
 
 
+def conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """Reference conv weight [Cout, Cin, kt, kh, kw] -> the K layout svr2_conv3d consumes:
+    [Cout, kt, Cin/64, kh, kw, 64] flattened (Cin % 64 == 0), or [Cout, kt, kh, kw, Cin] for the small-Cin
+    im2col path."""
+    cout, cin, kt, kh, kw = w.shape
+    if cin % 64:
+        return w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw * cin)
+    return w.reshape(cout, cin // 64, 64, kt, kh, kw).permute(0, 3, 1, 4, 5, 2).reshape(cout, kt * kh * kw * cin)
+
+
 def interleave_swiglu(w_gate: torch.Tensor, w_in: torch.Tensor) -> torch.Tensor:
     """Rows [8 gate | 8 in] per 16 (SVR2_EPI_SWIGLU).  w_*: [hidden, K]; hidden % 8 == 0."""
     h, k = w_gate.shape
@@ -229,7 +239,7 @@ def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y):
 def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad: int, pad_hw=(1, 1, 1, 1),
            carry: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
            resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w [cout_pad, kt*kh*kw*Cin] bf16 (tap-major, Cin fastest)."""
+    """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w = pad_weight(conv_weight(w5d)) ([cout_pad, kt*kh*kw*Cin])."""
     _bf16c(x, "conv3d.x"); _bf16c(w, "conv3d.w")
     if x.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
         raise HipError("conv3d: x must be contiguous [T,H,W,C]")

@@ -67,7 +67,7 @@ class VideoVAEHip:
             if k.endswith(".weight") and v.dim() == 5:
                 name = k[: -len(".weight")]
                 cout, cin, kt, kh, kw = v.shape
-                w = v.detach().to(dev).permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw * cin)
+                w = hip.conv_weight(v.detach().to(dev))
                 ent = {"cout": cout, "cin": cin, "k": (kt, kh, kw), "bias": f32(params[name + ".bias"])}
                 if cin % 64 == 0:
                     ent["w"] = hip.pad_weight(w)

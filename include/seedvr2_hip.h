@@ -90,7 +90,8 @@ int svr2_gemm(const svr2_gemm_desc* d, void* stream);
  *   x      bf16 [T, Hi, Wi, Cin]  current temporal chunk
  *   carry  bf16 [npad, Hi, Wi, Cin] previous chunk's last (kt - st) frames, or NULL:
  *          NULL => the head is padded with `npad` copies of frame 0 (first chunk: 2*pad_t)
- *   w      bf16 [cout_pad, kt, kh, kw, Cin]  (cout_pad = round_up(Cout,128), extra rows zero)
+ *   w      bf16 [cout_pad, kt, Cin/64, kh, kw, 64]  (cout_pad = round_up(Cout,128), extra rows zero): 64-channel
+ *          slices innermost, spatial taps next, so one slice's taps hit the same cache lines back to back
  *   y      bf16 [To, Ho, Wo, Cout],  To = (T + npad - kt)/st + 1, Ho = (Hi + pad_h0 + pad_h1 - kh)/sh + 1 ...
  *   resid  optional bf16 [To,Ho,Wo,Cout] added after bias (ResnetBlock3D skip, attn_video_vae.py:360)
  *   Cin % 64 == 0 (small-Cin layers go through svr2_im2col3d + svr2_gemm).

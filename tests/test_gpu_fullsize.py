@@ -49,7 +49,8 @@ def test_conv3d_delta_input_fullsize(pkg, gpu):
            ("c", 1, 500, 700, 31)]
     for src, t, y, xx, c in hot:
         (x if src == "x" else carry)[t, y, xx, c] = 1.0
-    out = hip.conv3d(x, hip.pad_weight(wt.reshape(C, -1)), C, (3, 3, 3), npad=2, carry=carry, bias=bias)
+    out = hip.conv3d(x, hip.pad_weight(hip.conv_weight(wt.permute(0, 4, 1, 2, 3))), C, (3, 3, 3), npad=2, carry=carry,
+                     bias=bias)
     b16 = bias.to(torch.bfloat16)
     # padded frame index p: carry frames 0,1 ; chunk frame t -> p = t + 2 ; output t' reads p in [t', t'+2]
     touched = torch.zeros(T, H, W, dtype=torch.bool, device=gpu)

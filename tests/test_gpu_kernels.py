@@ -113,7 +113,7 @@ def test_conv3d(pkg, gpu, case):
     res = rnd(*ref.shape, seed=24) if with_res else None
     if with_res:
         ref = ref + res
-    out = hip.conv3d(dev_bf16(x, gpu), hip.pad_weight(w.reshape(Cout, -1).to(gpu)), Cout, k, s, npad=npad,
+    out = hip.conv3d(dev_bf16(x, gpu), hip.pad_weight(hip.conv_weight(w.permute(0, 4, 1, 2, 3)).to(gpu)), Cout, k, s, npad=npad,
                      pad_hw=pad_hw, carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
                      resid=None if res is None else dev_bf16(res, gpu))
     assert_close(out, ref, f"conv3d {case}")
