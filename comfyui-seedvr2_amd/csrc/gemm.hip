@@ -406,8 +406,10 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
 
 extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
-    SVR2_CHECK(d->Cin > 0 && d->Cin % BK == 0, SVR2_E_SHAPE, "svr2_conv3d: Cin %% 64 != 0 (Cin=%d); use svr2_im2col3d",
-               d->Cin);
+    const bool tiled = d->w_layout == SVR2_WL_TILED_128x32;
+    SVR2_CHECK(d->w_layout == SVR2_WL_ROWS || tiled, SVR2_E_ARG, "svr2_conv3d: unknown w_layout %d", d->w_layout);
+    SVR2_CHECK(d->Cin > 0 && d->Cin % (tiled ? 32 : BK) == 0, SVR2_E_SHAPE,
+               "svr2_conv3d: Cin %% %d != 0 (Cin=%d); use svr2_im2col3d", tiled ? 32 : BK, d->Cin);
     SVR2_CHECK(d->Cout > 0 && (d->Cout % 8 == 0 || d->resid == nullptr), SVR2_E_SHAPE,
                "svr2_conv3d: Cout %% 8 != 0 needs resid == NULL (Cout=%d)", d->Cout);
     SVR2_CHECK(d->kt >= 1 && d->kh >= 1 && d->kw >= 1 && d->st >= 1 && d->sh >= 1 && d->sw >= 1 && d->npad >= 0,
@@ -436,5 +438,18 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
     a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
     a.cg.To = d->To; a.cg.Ho = d->Ho; a.cg.Wo = d->Wo;
+    // halo-resident kernel (conv_halo.hip): 3x3 spatial taps, stride 1, zero padding 1 on every side
+    const bool halo_shape = d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pad_h0 == 1 &&
+                            d->pad_w0 == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
+    if (tiled) {
+        SVR2_CHECK(halo_shape, SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_TILED_128x32 needs a 3x3 stride-1 pad-1 conv");
+        a.cg.wtiled = 1;
+        return conv_halo_launch(a, (hipStream_t)stream);
+    }
+    const char* he = getenv("SVR2_CONV_HALO");   // 0: never, 1 (default): large launches, 2: whenever the shape fits
+    const int halo = he ? atoi(he) : 1;
+    const long long ptiles = (long long)d->To * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 256);
+    if (halo && halo_shape && d->Cout % 256 == 0 && (ptiles >= 256 || halo == 2))
+        return conv_halo_launch(a, (hipStream_t)stream);
     return launch<A_CONV, SVR2_EPI_BIAS>(a, (hipStream_t)stream);
 }

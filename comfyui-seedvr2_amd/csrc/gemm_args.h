@@ -10,6 +10,8 @@ struct ConvGeom {
     const bf16* carry;
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
     int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
+    int wtiled;                    // W is in SVR2_WL_TILED_128x32 (conv_halo.hip only)
+    int dbg;                       // timing experiments only (SVR2_HALO_DBG): results are wrong when set
 };
 
 struct KArgs {
@@ -62,5 +64,7 @@ __device__ __forceinline__ int tile_row_to_m(const KArgs& a, int tm, int row) {
 
 // implemented in gemm2.hip: 256-row tiles, 128x64 per wave, BK = 32, 3-deep DMA ring
 int gemm2_launch(int amode, int epi, KArgs a, hipStream_t s);
+// implemented in conv_halo.hip: halo-resident stride-1 3x3(xkt) conv
+int conv_halo_launch(KArgs a, hipStream_t s);
 
 }  // namespace svr2

@@ -47,6 +47,7 @@ class Conv3dDesc(C.Structure):
         ("npad", C.c_int32), ("pad_h0", C.c_int32), ("pad_w0", C.c_int32),
         ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("zero_page", C.c_void_p),
+        ("w_layout", C.c_int32),
     ]
 
 
@@ -151,6 +152,28 @@ def conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(cout, cin // 64, 64, kt, kh, kw).permute(0, 3, 1, 4, 5, 2).reshape(cout, kt * kh * kw * cin)
 
 
+WL_ROWS, WL_TILED_128x32 = 0, 1
+
+
+def conv_weight_tiled(w: torch.Tensor) -> torch.Tensor:
+    """Reference conv weight [Cout, Cin, kt, 3, 3] -> SVR2_WL_TILED_128x32 (include/seedvr2_hip.h):
+    bf16 [cout_pad/128, kt, Cin/32, kh, kw, 128, 32], each [128, 32] tile in LDS-image order (chunk slot s of row r
+    holds channels 8*(s ^ f(r)), f(r) = {0,2,3,1}[(r>>2)&3]).  Returned as [cout_pad, kt*kh*kw*Cin]."""
+    cout, cin, kt, kh, kw = w.shape
+    if cin % 32:
+        raise HipError("conv_weight_tiled: Cin % 32 != 0")
+    cp = (cout + 127) // 128 * 128
+    wp = torch.zeros(cp, cin, kt, kh, kw, dtype=torch.bfloat16, device=w.device)
+    wp[:cout] = w.to(torch.bfloat16)
+    # [nb, r, cs, s, e, kt, kh, kw] -> [nb, kt, cs, kh, kw, r, s, e]
+    t = wp.reshape(cp // 128, 128, cin // 32, 4, 8, kt, kh, kw).permute(0, 5, 2, 6, 7, 1, 3, 4)
+    r = torch.arange(128, device=w.device)
+    f = torch.tensor([0, 2, 3, 1], device=w.device)[(r >> 2) & 3]
+    src = torch.arange(4, device=w.device)[None, :] ^ f[:, None]                 # [128, 4]: slot s <- chunk s ^ f(r)
+    idx = src[None, None, None, None, None, :, :, None].expand(cp // 128, kt, cin // 32, kh, kw, 128, 4, 8)
+    return torch.gather(t, 6, idx).contiguous().reshape(cp, kt * kh * kw * cin)
+
+
 def interleave_swiglu(w_gate: torch.Tensor, w_in: torch.Tensor) -> torch.Tensor:
     """Rows [8 gate | 8 in] per 16 (SVR2_EPI_SWIGLU).  w_*: [hidden, K]; hidden % 8 == 0."""
     h, k = w_gate.shape
@@ -219,7 +242,7 @@ def conv_out_size(t, hi, wi, k, s, npad, pad_hw):
     return to, ho, wo
 
 
-def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y):
+def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y, w_layout=WL_ROWS):
     T, Hi, Wi, Cin = x.shape
     To, Ho, Wo = conv_out_size(T, Hi, Wi, k, s, npad, pad_hw)
     d = Conv3dDesc()
@@ -233,13 +256,16 @@ def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y):
     d.npad, d.pad_h0, d.pad_w0 = npad, pad_hw[0], pad_hw[2]
     d.To, d.Ho, d.Wo = To, Ho, Wo
     d.zero_page = zero_page(x.device).data_ptr()
+    d.w_layout = w_layout
     return d, (To, Ho, Wo)
 
 
 def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad: int, pad_hw=(1, 1, 1, 1),
            carry: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-           resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w = pad_weight(conv_weight(w5d)) ([cout_pad, kt*kh*kw*Cin])."""
+           resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           w_layout: int = WL_ROWS) -> torch.Tensor:
+    """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w = pad_weight(conv_weight(w5d)) ([cout_pad, kt*kh*kw*Cin]), or
+    conv_weight_tiled(w5d) with w_layout = WL_TILED_128x32."""
     _bf16c(x, "conv3d.x"); _bf16c(w, "conv3d.w")
     if x.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
         raise HipError("conv3d: x must be contiguous [T,H,W,C]")
@@ -260,7 +286,7 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
     _f32c(bias, "conv3d.bias", cout)
     if resid is not None and (tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
         raise HipError("conv3d: resid must match the output shape")
-    d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out)
+    d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out, w_layout)
     _check(lib().svr2_conv3d(C.byref(d), _stream()), "svr2_conv3d")
     return out
 

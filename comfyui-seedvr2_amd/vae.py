@@ -67,13 +67,14 @@ class VideoVAEHip:
             if k.endswith(".weight") and v.dim() == 5:
                 name = k[: -len(".weight")]
                 cout, cin, kt, kh, kw = v.shape
-                w = hip.conv_weight(v.detach().to(dev))
                 ent = {"cout": cout, "cin": cin, "k": (kt, kh, kw), "bias": f32(params[name + ".bias"])}
                 if cin % 64 == 0:
-                    ent["w"] = hip.pad_weight(w)
+                    # the K layout depends on the kernel that will run the layer (stride / padding are call-site
+                    # facts): built on first use by _conv_weight(), then the 5-D copy is dropped
+                    ent["w5"] = v.detach().to(device=dev, dtype=torch.bfloat16)
                 else:  # small-Cin layers (3, 16): explicit im2col + GEMM
                     ent["kpad"] = (kt * kh * kw * cin + 63) // 64 * 64
-                    ent["w"] = hip.pad_weight(w, ent["kpad"])
+                    ent["w"] = hip.pad_weight(hip.conv_weight(v.detach().to(dev)), ent["kpad"])
                 self.convs[name] = ent
             elif k.endswith(".weight") and v.dim() == 1:
                 name = k[: -len(".weight")]
@@ -88,6 +89,18 @@ class VideoVAEHip:
                                 "b_out": f32(params[f"{a}.to_out.0.bias"]), "c": wq.shape[1]}
 
     # ------------------------------------------------------------------ primitives
+    @staticmethod
+    def _conv_weight(c: dict, stride, pad_hw) -> None:
+        """Pick the weight layout of a Cin % 64 == 0 conv on first use: the 3x3, stride-1, pad-1 layers whose Cout is
+        not a multiple of 256 run on the halo-resident 512-pixel x 128-channel kernel (SVR2_WL_TILED_128x32); the
+        rest use the row layout (halo-resident 256 x 256 kernel or the tap-staged kernels, chosen by the library)."""
+        kt, kh, kw = c["k"]
+        tiled = ((kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and tuple(pad_hw) == (1, 1, 1, 1)
+                 and c["cout"] % 256 != 0)
+        w5 = c.pop("w5")
+        c["layout"] = hip.WL_TILED_128x32 if tiled else hip.WL_ROWS
+        c["w"] = hip.conv_weight_tiled(w5) if tiled else hip.pad_weight(hip.conv_weight(w5))
+
     def _conv(self, name: str, x: torch.Tensor, st: _State, stride=(1, 1, 1), pad_hw=None,
               resid: Optional[torch.Tensor] = None) -> torch.Tensor:
         c = self.convs[name]
@@ -106,8 +119,10 @@ class VideoVAEHip:
             if resid is not None:
                 raise hip.HipError("small-Cin conv has no residual path")
         else:
+            if "w" not in c:
+                self._conv_weight(c, stride, pad_hw)
             y = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
-                           bias=c["bias"], resid=resid)
+                           bias=c["bias"], resid=resid, w_layout=c["layout"])
         if keep > 0 and not st.last:
             # carry the last `keep` input frames to the next chunk  [ref: causal_inflation_lib.py:266-278].  The old
             # carry is released first (stream-ordered reuse: the conv that reads it is already enqueued).
@@ -155,6 +170,8 @@ class VideoVAEHip:
         c = self.convs[name + ".upscale_conv"]
         T, H, W, Cc = x.shape
         drop = tz == 2 and not st.active  # remove_head on the first chunk  [ref: attn_video_vae.py:152-153]
+        if "w" not in c:
+            self._conv_weight(c, (1, 1, 1), (0, 0, 0, 0))   # 1x1x1: plain [N, K] rows
         y = hip.gemm(x.view(T * H * W, Cc), c["w"], c["cout"], epilogue=hip.EPI_PIXSHUF3D, bias=c["bias"],
                      pixshuf=(T, H, W, Cc, tz, drop))
         return self._conv(name + ".conv", y, st)

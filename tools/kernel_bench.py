@@ -52,15 +52,20 @@ def bench_gemm(M, N, K, epi="bias"):
     print(f"gemm[{epi}] M={M} N={N} K={K}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s", flush=True)
 
 
-def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3)):
+def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False):
     x = rb(T, H, W, Cin)
-    w = hip.pad_weight(rb(Cout, k[0] * k[1] * k[2] * Cin, scale=0.02))
+    if tiled:
+        w = hip.conv_weight_tiled(rb(Cout, Cin, *k, scale=0.02))
+    else:
+        w = hip.pad_weight(rb(Cout, k[0] * k[1] * k[2] * Cin, scale=0.02))
     b = torch.zeros(Cout, device=dev)
     out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
-    fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out)
+    fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out,
+                            w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS)
     t = timeit(fn)
     fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
-    print(f"conv3d T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
+    tag = "tiled" if tiled else f"halo={os.environ.get('SVR2_CONV_HALO', '1')}"
+    print(f"conv3d[{tag}] T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
 def bench_attn(grid, method, H=20):
@@ -107,6 +112,26 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "halo" in which:   # A/B of conv_halo.hip against the tap-staged kernels on the shapes of the 4K decoder
+        for hv in ("0", "1"):
+            os.environ["SVR2_CONV_HALO"] = hv
+            bench_conv(5, 272, 480, 512, 512)
+            bench_conv(5, 544, 960, 512, 512)
+            bench_conv(5, 1088, 1920, 256, 256)
+            bench_conv(4, 1080, 1920, 512, 256)
+        os.environ["SVR2_CONV_HALO"] = "1"
+        bench_conv(4, 2160, 3840, 128, 128)
+        bench_conv(4, 2160, 3840, 128, 128, tiled=True)
+        bench_conv(4, 2160, 3840, 256, 128)
+        bench_conv(4, 2160, 3840, 256, 128, tiled=True)
+        bench_conv(4, 2160, 3840, 128, 3, tiled=True)
+    if "halodbg" in which:   # timing experiments (wrong results): which part of the K loop costs what
+        for dbg in ("0", "1", "2", "4", "6", "7", "15"):
+            os.environ["SVR2_HALO_DBG"] = dbg
+            print("SVR2_HALO_DBG =", dbg, "(1 no barrier, 2 no W DMA, 4 no halo DMA, 8 no vmcnt wait)")
+            bench_conv(5, 544, 960, 512, 512)
+            bench_conv(4, 2160, 3840, 128, 128, tiled=True)
+        os.environ["SVR2_HALO_DBG"] = "0"
     if "conv" in which:
         bench_conv(5, 136, 240, 512, 512)
         bench_conv(5, 272, 480, 512, 512)
