@@ -304,7 +304,7 @@ def main():
                        "lr": [hin, win], "out": [th, tw], "padded": [ph, pw], "parallelism": f"frame-chunk x{world}",
                        "algorithmic_tflop_per_step": {"vae_encode": enc_f / 1e12, "dit_gemm": dit_f / 1e12,
                                                       "vae_decode": dec_f / 1e12}},
-            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM causal conv3d (gemm2_kernel<A_CONV,*,256|128> + gemm_kernel<A_CONV,*,128>)",
+            "roofline": {"bound": "mfma", "kernel": "causal conv3d: conv_halo_kernel<16,256|32,128> (3x3 stride 1) + gemm2_kernel/gemm_kernel<A_CONV> (strided, 1x1x1)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic_cfg3.json)",

@@ -438,18 +438,11 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
     a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
     a.cg.To = d->To; a.cg.Ho = d->Ho; a.cg.Wo = d->Wo;
-    // halo-resident kernel (conv_halo.hip): 3x3 spatial taps, stride 1, zero padding 1 on every side
-    const bool halo_shape = d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pad_h0 == 1 &&
-                            d->pad_w0 == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
-    if (tiled) {
+    if (tiled) {   // halo-resident kernel (conv_halo.hip): 3x3 spatial taps, stride 1, zero padding 1 on every side
+        const bool halo_shape = d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
+                                d->pad_h0 == 1 && d->pad_w0 == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
         SVR2_CHECK(halo_shape, SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_TILED_128x32 needs a 3x3 stride-1 pad-1 conv");
-        a.cg.wtiled = 1;
         return conv_halo_launch(a, (hipStream_t)stream);
     }
-    const char* he = getenv("SVR2_CONV_HALO");   // 0: never, 1 (default): large launches, 2: whenever the shape fits
-    const int halo = he ? atoi(he) : 1;
-    const long long ptiles = (long long)d->To * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 256);
-    if (halo && halo_shape && d->Cout % 256 == 0 && (ptiles >= 256 || halo == 2))
-        return conv_halo_launch(a, (hipStream_t)stream);
     return launch<A_CONV, SVR2_EPI_BIAS>(a, (hipStream_t)stream);
 }

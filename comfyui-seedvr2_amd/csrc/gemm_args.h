@@ -10,8 +10,6 @@ struct ConvGeom {
     const bf16* carry;
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
     int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
-    int wtiled;                    // W is in SVR2_WL_TILED_128x32 (conv_halo.hip only)
-    int dbg;                       // timing experiments only (SVR2_HALO_DBG): results are wrong when set
 };
 
 struct KArgs {

@@ -157,7 +157,7 @@ WL_ROWS, WL_TILED_128x32 = 0, 1
 
 def conv_weight_tiled(w: torch.Tensor) -> torch.Tensor:
     """Reference conv weight [Cout, Cin, kt, 3, 3] -> SVR2_WL_TILED_128x32 (include/seedvr2_hip.h):
-    bf16 [cout_pad/128, kt, Cin/32, kh, kw, 128, 32], each [128, 32] tile in LDS-image order (chunk slot s of row r
+    bf16 [cout_pad/128, kt, Cin/32, kw, kh, 128, 32], each [128, 32] tile in LDS-image order (chunk slot s of row r
     holds channels 8*(s ^ f(r)), f(r) = {0,2,3,1}[(r>>2)&3]).  Returned as [cout_pad, kt*kh*kw*Cin]."""
     cout, cin, kt, kh, kw = w.shape
     if cin % 32:
@@ -165,12 +165,12 @@ def conv_weight_tiled(w: torch.Tensor) -> torch.Tensor:
     cp = (cout + 127) // 128 * 128
     wp = torch.zeros(cp, cin, kt, kh, kw, dtype=torch.bfloat16, device=w.device)
     wp[:cout] = w.to(torch.bfloat16)
-    # [nb, r, cs, s, e, kt, kh, kw] -> [nb, kt, cs, kh, kw, r, s, e]
-    t = wp.reshape(cp // 128, 128, cin // 32, 4, 8, kt, kh, kw).permute(0, 5, 2, 6, 7, 1, 3, 4)
+    # [nb, r, cs, s, e, kt, kh, kw] -> [nb, kt, cs, kw, kh, r, s, e]
+    t = wp.reshape(cp // 128, 128, cin // 32, 4, 8, kt, kh, kw).permute(0, 5, 2, 7, 6, 1, 3, 4)
     r = torch.arange(128, device=w.device)
     f = torch.tensor([0, 2, 3, 1], device=w.device)[(r >> 2) & 3]
     src = torch.arange(4, device=w.device)[None, :] ^ f[:, None]                 # [128, 4]: slot s <- chunk s ^ f(r)
-    idx = src[None, None, None, None, None, :, :, None].expand(cp // 128, kt, cin // 32, kh, kw, 128, 4, 8)
+    idx = src[None, None, None, None, None, :, :, None].expand(cp // 128, kt, cin // 32, kw, kh, 128, 4, 8)
     return torch.gather(t, 6, idx).contiguous().reshape(cp, kt * kh * kw * cin)
 
 

@@ -91,12 +91,11 @@ class VideoVAEHip:
     # ------------------------------------------------------------------ primitives
     @staticmethod
     def _conv_weight(c: dict, stride, pad_hw) -> None:
-        """Pick the weight layout of a Cin % 64 == 0 conv on first use: the 3x3, stride-1, pad-1 layers whose Cout is
-        not a multiple of 256 run on the halo-resident 512-pixel x 128-channel kernel (SVR2_WL_TILED_128x32); the
-        rest use the row layout (halo-resident 256 x 256 kernel or the tap-staged kernels, chosen by the library)."""
+        """Pick the weight layout of a Cin % 64 == 0 conv on first use: the 3x3, stride-1, pad-1 layers run on the
+        halo-resident kernel (SVR2_WL_TILED_128x32); the rest (strided downsamplers, 1x1x1 shortcuts) use the row
+        layout of the tap-staged kernels."""
         kt, kh, kw = c["k"]
-        tiled = ((kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and tuple(pad_hw) == (1, 1, 1, 1)
-                 and c["cout"] % 256 != 0)
+        tiled = (kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and tuple(pad_hw) == (1, 1, 1, 1)
         w5 = c.pop("w5")
         c["layout"] = hip.WL_TILED_128x32 if tiled else hip.WL_ROWS
         c["w"] = hip.conv_weight_tiled(w5) if tiled else hip.pad_weight(hip.conv_weight(w5))

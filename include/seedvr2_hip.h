@@ -96,11 +96,12 @@ int svr2_gemm(const svr2_gemm_desc* d, void* stream);
  *   resid  optional bf16 [To,Ho,Wo,Cout] added after bias (ResnetBlock3D skip, attn_video_vae.py:360)
  *   Cin % 64 == 0 (small-Cin layers go through svr2_im2col3d + svr2_gemm).
  *
- *   w_layout = SVR2_WL_TILED_128x32 selects the halo-resident 512-pixel x 128-channel kernel for the
- *   kh = kw = 3, stride-1, pad-1 convs with few output channels (Cout <= 128 per column block); it needs
- *   Cin % 32 == 0 and w as bf16 [cout_pad/128][kt][Cin/32][kh][kw][128][32] where each [128][32] tile is stored
- *   in LDS-image order: the 16-byte chunk at (row r, slot s) holds channels 8*(s ^ f(r)) .. +8,
- *   f(r) = {0,2,3,1}[(r >> 2) & 3]  (every weight DMA is then one linear KiB).
+ *   w_layout = SVR2_WL_TILED_128x32 selects the halo-resident kernel (input halo of a pixel patch kept in LDS,
+ *   the nine spatial taps are shifted LDS reads) for the kh = kw = 3, stride-1, pad-1 convs; it needs
+ *   Cin % 32 == 0 and w as bf16 [cout_pad/128][kt][Cin/32][kw][kh][128][32] (kx outer, ky inner: the three ky
+ *   tiles of one kx column are 24 contiguous KiB) where each [128][32] tile is stored in LDS-image order: the
+ *   16-byte chunk at (row r, slot s) holds channels 8*(s ^ f(r)) .. +8, f(r) = {0,2,3,1}[(r >> 2) & 3]
+ *   (every weight DMA is then one linear KiB).
  */
 enum { SVR2_WL_ROWS = 0, SVR2_WL_TILED_128x32 = 1 };
 

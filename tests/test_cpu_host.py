@@ -184,7 +184,7 @@ def test_argument_validation_without_gpu(pkg):
 
 
 def test_conv_weight_tiled_layout(pkg):
-    """SVR2_WL_TILED_128x32 (include/seedvr2_hip.h): tile (nb, kt, cs, ky, kx), row r, slot s, element e holds
+    """SVR2_WL_TILED_128x32 (include/seedvr2_hip.h): tile (nb, kt, cs, kx, ky), row r, slot s, element e holds
     w[nb*128 + r, cs*32 + 8*(s ^ f(r)) + e, kt, ky, kx], f(r) = {0,2,3,1}[(r>>2)&3]; rows >= Cout are zero."""
     g = torch.Generator().manual_seed(5)
     cout, cin, kt = 130, 64, 3
@@ -193,7 +193,7 @@ def test_conv_weight_tiled_layout(pkg):
     f = [0, 2, 3, 1]
     rng = np.random.default_rng(0)
     for _ in range(300):
-        nb, a, cs, ky, kx, r, s, e = (int(rng.integers(n)) for n in (2, kt, cin // 32, 3, 3, 128, 4, 8))
+        nb, a, cs, kx, ky, r, s, e = (int(rng.integers(n)) for n in (2, kt, cin // 32, 3, 3, 128, 4, 8))
         n, c = nb * 128 + r, cs * 32 + 8 * (s ^ f[(r >> 2) & 3]) + e
         want = w[n, c, a, ky, kx].item() if n < cout else 0.0
-        assert t[nb, a, cs, ky, kx, r, s, e].item() == want
+        assert t[nb, a, cs, kx, ky, r, s, e].item() == want

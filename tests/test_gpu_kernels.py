@@ -120,25 +120,26 @@ def test_conv3d(pkg, gpu, case):
 
 
 HALO_CASES = [
-    # T, H, W, Cin, Cout, kt, with_carry, resid, tiled
-    (2, 16, 16, 64, 256, 3, False, False, False),
-    (3, 20, 37, 128, 256, 3, True, True, False),      # ragged patches on both edges
-    (2, 33, 18, 64, 512, 1, False, True, False),      # kt = 1 (spatial-only conv), two column blocks
-    (1, 7, 5, 192, 256, 3, True, False, False),       # image smaller than one patch
-    (2, 16, 32, 32, 128, 3, False, False, True),
-    (3, 20, 37, 128, 128, 3, True, True, True),
-    (2, 33, 70, 96, 64, 1, False, True, True),
-    (2, 18, 40, 128, 3, 3, True, False, True),        # conv_out: Cout = 3
-    (1, 9, 11, 64, 200, 3, False, False, True),       # two 128-column blocks, the second ragged
+    # T, H, W, Cin, Cout, kt, with_carry, resid
+    (2, 16, 16, 64, 256, 3, False, False),
+    (3, 20, 37, 128, 256, 3, True, True),      # ragged patches on both edges
+    (2, 33, 18, 64, 512, 1, False, True),      # kt = 1 (spatial-only conv), two 256-column blocks
+    (1, 7, 5, 192, 256, 3, True, False),       # image smaller than one patch
+    (2, 16, 32, 32, 128, 3, False, False),
+    (3, 20, 37, 128, 128, 3, True, True),
+    (2, 33, 70, 96, 64, 1, False, True),
+    (2, 18, 40, 128, 3, 3, True, False),       # conv_out: Cout = 3
+    (1, 9, 11, 64, 200, 3, False, False),      # two 128-column blocks, the second ragged
+    (2, 40, 72, 64, 384, 3, True, True),       # three 128-column blocks
 ]
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_conv3d_halo_resident(pkg, gpu, case, monkeypatch):
-    """conv_halo.hip (halo kept in LDS, nine shifted reads): both geometries, ragged edges, carry, resid."""
+def test_conv3d_halo_resident(pkg, gpu, case):
+    """conv_halo.hip (halo kept in LDS, nine shifted reads, SVR2_WL_TILED_128x32 weights): both geometries, ragged
+    edges, carry, resid; also against the tap-staged kernel on the same inputs."""
     hip = pkg.hip
-    monkeypatch.setenv("SVR2_CONV_HALO", "2")
-    T, H, W, Cin, Cout, kt, with_carry, with_res, tiled = case
+    T, H, W, Cin, Cout, kt, with_carry, with_res = case
     k, s, npad, pad_hw = (kt, 3, 3), (1, 1, 1), kt - 1, (1, 1, 1, 1)
     x = rnd(T, H, W, Cin, seed=25)
     w = rnd(Cout, *k, Cin, seed=26, scale=1 / math.sqrt(Cin * 9 * kt))
@@ -149,17 +150,12 @@ def test_conv3d_halo_resident(pkg, gpu, case, monkeypatch):
     if with_res:
         ref = ref + res
     w5 = w.permute(0, 4, 1, 2, 3)
-    wd = hip.conv_weight_tiled(w5.to(gpu)) if tiled else hip.pad_weight(hip.conv_weight(w5).to(gpu))
-    out = hip.conv3d(dev_bf16(x, gpu), wd, Cout, k, s, npad=npad, pad_hw=pad_hw,
-                     carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
-                     resid=None if res is None else dev_bf16(res, gpu),
-                     w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS)
+    kw = dict(npad=npad, pad_hw=pad_hw, carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
+              resid=None if res is None else dev_bf16(res, gpu))
+    out = hip.conv3d(dev_bf16(x, gpu), hip.conv_weight_tiled(w5.to(gpu)), Cout, k, s, w_layout=hip.WL_TILED_128x32, **kw)
     assert_close(out, ref, f"conv3d halo {case}")
-    if not tiled:   # bit-identical to the gemm2/gemm path is not required (different summation order), but close:
-        monkeypatch.setenv("SVR2_CONV_HALO", "0")
-        out0 = hip.conv3d(dev_bf16(x, gpu), wd, Cout, k, s, npad=npad, pad_hw=pad_hw,
-                          carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
-                          resid=None if res is None else dev_bf16(res, gpu))
+    if Cin % 64 == 0 and (Cout % 8 == 0 or not with_res):
+        out0 = hip.conv3d(dev_bf16(x, gpu), hip.pad_weight(hip.conv_weight(w5).to(gpu)), Cout, k, s, **kw)
         assert_close(out, out0.float().cpu(), f"conv3d halo vs tap-staged {case}")
 
 

@@ -64,7 +64,7 @@ def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False):
                             w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS)
     t = timeit(fn)
     fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
-    tag = "tiled" if tiled else f"halo={os.environ.get('SVR2_CONV_HALO', '1')}"
+    tag = "halo/tiled" if tiled else "tap-staged"
     print(f"conv3d[{tag}] T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
@@ -112,26 +112,13 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
-    if "halo" in which:   # A/B of conv_halo.hip against the tap-staged kernels on the shapes of the 4K decoder
-        for hv in ("0", "1"):
-            os.environ["SVR2_CONV_HALO"] = hv
-            bench_conv(5, 272, 480, 512, 512)
-            bench_conv(5, 544, 960, 512, 512)
-            bench_conv(5, 1088, 1920, 256, 256)
-            bench_conv(4, 1080, 1920, 512, 256)
-        os.environ["SVR2_CONV_HALO"] = "1"
-        bench_conv(4, 2160, 3840, 128, 128)
-        bench_conv(4, 2160, 3840, 128, 128, tiled=True)
-        bench_conv(4, 2160, 3840, 256, 128)
-        bench_conv(4, 2160, 3840, 256, 128, tiled=True)
+    if "halo" in which:   # conv_halo.hip (tiled weights) against the tap-staged kernels on the 4K decoder shapes
+        for shp in ((5, 272, 480, 512, 512), (5, 544, 960, 512, 512), (5, 1088, 1920, 256, 256),
+                    (4, 1080, 1920, 512, 256), (4, 2160, 3840, 128, 128), (4, 2160, 3840, 256, 128),
+                    (4, 2160, 3840, 256, 256)):
+            bench_conv(*shp)
+            bench_conv(*shp, tiled=True)
         bench_conv(4, 2160, 3840, 128, 3, tiled=True)
-    if "halodbg" in which:   # timing experiments (wrong results): which part of the K loop costs what
-        for dbg in ("0", "1", "2", "4", "6", "7", "15"):
-            os.environ["SVR2_HALO_DBG"] = dbg
-            print("SVR2_HALO_DBG =", dbg, "(1 no barrier, 2 no W DMA, 4 no halo DMA, 8 no vmcnt wait)")
-            bench_conv(5, 544, 960, 512, 512)
-            bench_conv(4, 2160, 3840, 128, 128, tiled=True)
-        os.environ["SVR2_HALO_DBG"] = "0"
     if "conv" in which:
         bench_conv(5, 136, 240, 512, 512)
         bench_conv(5, 272, 480, 512, 512)
