@@ -112,6 +112,10 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "halopmc" in which:   # few launches of the three dominant halo-conv shapes for counter collection
+        bench_conv(4, 2160, 3840, 128, 128, tiled=True)
+        bench_conv(4, 1080, 1920, 256, 256, tiled=True)
+        bench_conv(4, 1080, 1920, 512, 512, tiled=True)
     if "halo" in which:   # conv_halo.hip (tiled weights) against the tap-staged kernels on the 4K decoder shapes
         for shp in ((5, 272, 480, 512, 512), (5, 544, 960, 512, 512), (5, 1088, 1920, 256, 256),
                     (4, 1080, 1920, 512, 256), (4, 2160, 3840, 128, 128), (4, 2160, 3840, 256, 128),
