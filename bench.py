@@ -202,6 +202,10 @@ def main():
     T, hin, win, res, overlap, desc = WORKLOADS[args.workload]
     t_build = time.time()
     vcfg = pkg.vae.VAEConfig()
+    if os.environ.get("SVR2_DECODE_SPLIT"):   # A/B of the temporal chunk sizes (results do not depend on them)
+        vcfg.decode_split = int(os.environ["SVR2_DECODE_SPLIT"])
+    if os.environ.get("SVR2_ENCODE_SPLIT"):
+        vcfg.encode_split = int(os.environ["SVR2_ENCODE_SPLIT"])
     vae = pkg.vae.VideoVAEHip(vcfg, pkg.vae.synthetic_state_dict(vcfg, dev, seed=1), dev)
     dcfg = pkg.dit.CFG_7B if args.workload == "cfg4" else pkg.dit.CFG_3B
     dit = pkg.dit.NaDiTHip(dcfg, pkg.dit.synthetic_state_dict(dcfg, dev, seed=2), dev)

@@ -45,12 +45,13 @@ template <int PW, int BN> struct GeoH {
     static constexpr int HPS = (HPW + 1) / 2;                           // ... issued on each of the super-steps 0, 1
     static constexpr int TAPB = BN * ROWB;                              // W bytes per tap
     static constexpr int WS_BYTES = 3 * TAPB;                           // W bytes per super-step (three ky taps)
-    static constexpr int NWP = WS_BYTES / 1024 / 4;                     // pieces per W wave per super-step
+    static constexpr int JN = BN >= 64 ? 4 : BN / 16;                   // 16-channel MFMA tiles per wave
+    static constexpr int NWN = BN >= 64 ? BN / 64 : 1;                  // waves along the channels
     static constexpr int RING = 2 * HALO_BYTES + 2 * WS_BYTES;
     static constexpr int EPI_LD = BN * 2 + 16;
     static constexpr int EPI_BYTES = BM * EPI_LD;
     static constexpr int LDS = RING > EPI_BYTES ? RING : EPI_BYTES;
-    static_assert((BM / 128) * (BN / 64) == 8 && LDS <= 160 * 1024, "geometry");
+    static_assert((BM / 128) * NWN == 8 && LDS <= 160 * 1024, "geometry");
 };
 
 template <int PW, int BN>
@@ -99,37 +100,45 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         }
     };
 
-    // ---- W loader (waves 0-3): NWP linear 1-KiB pieces per wave per super-step.  A 128-channel tile column is 24
-    //      contiguous KiB per super-step (ky-major, eight 16-row KiB blocks per ky); wave w streams blocks
-    //      [wsub*BPW, (wsub+1)*BPW) of every ky of column wcol  ->  LDS stage + ky*TAPB + wcol*8 KiB + block KiB.
-    constexpr int WPC = 4 / (BN / 128), BPW = 8 / WPC;   // W waves per tile column, blocks per wave per ky
-    const int wcol = wave / WPC, wsub = wave % WPC;
-    const char* wsrc = (const char*)a.W + (long long)(tn * (BN / 128) + wcol) * nss * (24 * 1024) + wsub * (BPW * 1024);
+    // ---- W loader (waves 0-3): linear 1-KiB pieces.  A 128-channel tile column is 24 contiguous KiB per super-step
+    //      (ky-major, eight 16-row KiB blocks per ky); wave w streams blocks [wsub*BPW, (wsub+1)*BPW) of every ky of
+    //      column wcol  ->  LDS stage + ky*TAPB + wcol*8 KiB + block KiB.  BN = 16 reads only the first block (rows
+    //      0..15) of every ky: three pieces, one each on waves 0..2.
+    constexpr int WPC = BN >= 128 ? 4 / (BN / 128) : 4, BPW = BN >= 128 ? 8 / WPC : 1;
+    const int wcol = BN >= 128 ? wave / WPC : 0, wsub = BN >= 128 ? wave % WPC : 0;
+    const int tcol = BN >= 128 ? tn * (BN / 128) + wcol : (tn * BN) / 128;       // 128-channel tile column read
+    const char* wsrc = (const char*)a.W + (long long)tcol * nss * (24 * 1024) + wsub * (BPW * 1024) +
+                       (BN >= 128 ? 0 : ((tn * BN) % 128) * ROWB);
     const unsigned l16 = lane * 16;
     char* const wdst = wring + wcol * 8192 + wsub * (BPW * 1024);
     auto issue_w = [&](int stage) {
+        if (BN >= 128) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int b = 0; b < BPW; ++b)
-                glds16(wsrc + (ky * 8192 + b * 1024) + l16, wdst + stage * G::WS_BYTES + ky * G::TAPB + b * 1024);
+                for (int b = 0; b < BPW; ++b)
+                    glds16(wsrc + (ky * 8192 + b * 1024) + l16, wdst + stage * G::WS_BYTES + ky * G::TAPB + b * 1024);
+        } else if (wave < 3) {
+            glds16(wsrc + wave * 8192 + l16, wring + stage * G::WS_BYTES + wave * G::TAPB);
+        }
         wsrc += 24 * 1024;
     };
 
     // ---- MFMA fragment coordinates
     constexpr int WPX = PW / 16;                   // waves along x
-    const int wm = wave / (BN / 64), wn = wave % (BN / 64);
+    constexpr int JN = G::JN;
+    const int wm = wave / G::NWN, wn = wave % G::NWN;
     const int wpy0 = (wm / WPX) * 8, wpx0 = (wm % WPX) * 16;
     const int frow = lane & 15, fq = lane >> 4;
     const int pix = frow < 4 ? 2 * frow : (frow < 12 ? 2 * frow - 7 : 2 * frow - 16);   // pi(frow)
     const int hxl = wpx0 + pix;                    // halo x of this lane's pixel under kx = 0
     const int rbase = wpy0 * HP + hxl;             // its halo row for the first row of the wave's band, tap (0,0)
     const int wfo = (wn * 64 + frow) * ROWB + ((fq ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3)) << 4);
-    f32x4 acc[8][4];
+    f32x4 acc[8][JN];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: whole halo of slice 0, W of super-step 0
     if (wrole) issue_w(0);
@@ -161,13 +170,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         for (int r = 0; r < 10; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            bf16x8 bfr[4];
+            bf16x8 bfr[JN];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) bfr[jn] = *(const bf16x8*)(sB + ky * G::TAPB + jn * 16 * ROWB);
+            for (int jn = 0; jn < JN; ++jn) bfr[jn] = *(const bf16x8*)(sB + ky * G::TAPB + jn * 16 * ROWB);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn)   // W fragment is the MFMA A operand: D[row = n][col = pixel]
+                for (int jn = 0; jn < JN; ++jn)   // W fragment is the MFMA A operand: D[row = n][col = pixel]
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jn], af[i + ky], acc[i][jn], 0, 0, 0);
         }
         __builtin_amdgcn_iglp_opt(1);
@@ -179,9 +188,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
     // ---- epilogue: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8 channels
     asm volatile("s_barrier" ::: "memory");
     {
-        f32x4 bv[4];
+        f32x4 bv[JN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < JN; ++j) {
             bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int n = n0 + wn * 64 + j * 16 + 4 * fq;
             if (a.bias) {
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < JN; ++j) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r] + bv[j][r]);
@@ -254,6 +263,8 @@ int launch_halo(KArgs a, hipStream_t s) {
 int conv_halo_launch(KArgs a, hipStream_t s) {
     // 256-channel column blocks read two 128-row W tile columns: only when Cout is a multiple of 256
     if (a.N % 256 == 0 && !getenv("SVR2_HALO_NARROW")) return launch_halo<16, 256>(a, s);
+    // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile
+    if (a.N <= 16 && !getenv("SVR2_HALO_NO_N16")) return launch_halo<64, 16>(a, s);
     return launch_halo<32, 128>(a, s);
 }
 

@@ -217,32 +217,50 @@ struct Im2colArgs {
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
     long long kpad;
 };
+// One thread = 8 consecutive K columns of one output pixel (one 16-byte store; a row of the col matrix is written
+// by kpad/8 consecutive lanes).  The (tap, channel) decomposition of the first column is divided out once and then
+// stepped; the gathers are 2-byte loads of a few neighbouring pixels (L1 hits).
 __global__ __launch_bounds__(256) void im2col3d_kernel(const Im2colArgs a) {
     const long long M = (long long)a.To * a.Ho * a.Wo;
-    const long long total = M * a.kpad;
+    const int cpr = (int)(a.kpad >> 3);                     // 16-byte chunks per row
+    const long long total = M * cpr;
     const int Kreal = a.kt * a.kh * a.kw * a.Cin;
     const long long frame = (long long)a.Hi * a.Wi * a.Cin;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int kcol = (int)(i % a.kpad);
-        const long long m = i / a.kpad;
-        float v = 0.f;
-        if (kcol < Kreal) {
-            const int c = kcol % a.Cin;
-            int tap = kcol / a.Cin;
-            const int kx = tap % a.kw; tap /= a.kw;
-            const int ky = tap % a.kh; const int kt = tap / a.kh;
-            const int x = (int)(m % a.Wo);
-            const long long t2 = m / a.Wo;
-            const int y = (int)(t2 % a.Ho), t = (int)(t2 / a.Ho);
-            const int iy = y * a.sh - a.pad_h0 + ky, ix = x * a.sw - a.pad_w0 + kx, it = t * a.st + kt;
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                const bf16* fb = it < a.npad ? (a.carry ? a.carry + (long long)it * frame : a.x)
-                                             : a.x + (long long)(it - a.npad) * frame;
-                v = bf2f(fb[((long long)iy * a.Wi + ix) * a.Cin + c]);
+        const int chunk = (int)(i % cpr);
+        const long long m = i / cpr;
+        const int x = (int)(m % a.Wo);
+        const long long t2 = m / a.Wo;
+        const int y = (int)(t2 % a.Ho), t = (int)(t2 / a.Ho);
+        const int iy0 = y * a.sh - a.pad_h0, ix0 = x * a.sw - a.pad_w0, it0 = t * a.st;
+        int kcol = chunk * 8;
+        int c = kcol % a.Cin, tap = kcol / a.Cin;
+        int kx = tap % a.kw;
+        tap /= a.kw;
+        int ky = tap % a.kh, kt = tap / a.kh;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e, ++kcol) {
+            float v = 0.f;
+            if (kcol < Kreal) {
+                const int iy = iy0 + ky, ix = ix0 + kx, it = it0 + kt;
+                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
+                    const bf16* fb = it < a.npad ? (a.carry ? a.carry + (long long)it * frame : a.x)
+                                                 : a.x + (long long)(it - a.npad) * frame;
+                    v = bf2f(fb[((long long)iy * a.Wi + ix) * a.Cin + c]);
+                }
+            }
+            o[e] = f2bf(v);
+            if (++c == a.Cin) {
+                c = 0;
+                if (++kx == a.kw) {
+                    kx = 0;
+                    if (++ky == a.kh) { ky = 0; ++kt; }
+                }
             }
         }
-        a.col[i] = f2bf(v);
+        *(bf16x8*)(a.col + m * a.kpad + chunk * 8) = o;
     }
 }
 
@@ -349,7 +367,7 @@ extern "C" int svr2_im2col3d(const svr2_conv3d_desc* d, void* col, int64_t kpad,
     a.T = d->T; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
     a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.npad = d->npad; a.pad_h0 = d->pad_h0; a.pad_w0 = d->pad_w0;
     a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.kpad = kpad;
-    const long long total = (long long)d->To * d->Ho * d->Wo * kpad;
+    const long long total = (long long)d->To * d->Ho * d->Wo * (kpad / 8);
     hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;

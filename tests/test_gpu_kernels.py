@@ -131,6 +131,9 @@ HALO_CASES = [
     (2, 18, 40, 128, 3, 3, True, False),       # conv_out: Cout = 3
     (1, 9, 11, 64, 200, 3, False, False),      # two 128-column blocks, the second ragged
     (2, 40, 72, 64, 384, 3, True, True),       # three 128-column blocks
+    (2, 35, 150, 64, 3, 3, False, False),      # 16-channel tiles: ragged 16 x 64 patches
+    (3, 16, 64, 128, 16, 3, True, True),
+    (1, 20, 70, 32, 8, 1, False, False),
 ]
 
 
