@@ -69,13 +69,14 @@ class KernelTimer:
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = fn(*a, **k)
+            res = fn(*a, **k)
             e1.record()
+            out = res[0] if isinstance(res, tuple) else res   # conv3d(..., gn_stats=True) returns (y, partial sums)
             f = flop_fn(out, *a, **k)
             self.pairs.append((e0, e1, f, (tuple(a[0].shape), tuple(out.shape), a[3], k.get("carry") is not None,
                                            k.get("resid") is not None)))
             self.flops += f
-            return out
+            return res
         return inner
 
     def summary(self):

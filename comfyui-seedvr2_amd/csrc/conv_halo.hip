@@ -210,6 +210,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
             }
     }
     __syncthreads();
+    // optional GroupNorm statistics of the tile (of the rounded bf16 outputs, the values the next norm reads): a
+    // thread always handles the same 8 channels (BN/8 divides the block size), so it keeps 8 (sum, sumsq) pairs
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
     for (int c = tid; c < G::BM * (BN / 8); c += G::NT) {
         const int row = c / (BN / 8), cc = c % (BN / 8);
         const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
@@ -225,13 +230,39 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
             for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
         }
         const long long dst = m * a.ldc + n;
-        if (n + 8 <= a.N) {
-            bf16x8 o;
+        bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        if (n + 8 <= a.N) {
             *(bf16x8*)(a.C + dst) = o;
         } else {
-            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = f2bf(v[e]);
+            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = o[e];
+        }
+        if (a.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r = bf2f(o[e]);
+                st_s[e] += r;
+                st_q[e] += r * r;
+            }
+        }
+    }
+    if (a.stats) {   // partial[frame][tile][2][N], folded over tiles by svr2_groupnorm_finalize (fixed order: deterministic)
+        constexpr int NV = BN / 8, RPT = G::NT / NV;
+        __syncthreads();                                   // the epilogue tile has been read
+        float* red = (float*)smem;                         // [NT][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid * 16 + e] = st_s[e];
+            red[tid * 16 + 8 + e] = st_q[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < NV * 16; i += G::NT) {
+            const int v = i >> 4, e = i & 15;
+            float acc2 = 0.f;
+            for (int r = 0; r < RPT; ++r) acc2 += red[(r * NV + v) * 16 + e];
+            const int n = n0 + v * 8 + (e & 7);
+            if (n < a.N) a.stats[(((long long)t * per_frame + rem) * 2 + (e >> 3)) * a.N + n] = acc2;
         }
     }
 }
@@ -262,9 +293,9 @@ int launch_halo(KArgs a, hipStream_t s) {
 // (Ho = Hi, Wo = Wi), any kt, Cin % 32 == 0, W in SVR2_WL_TILED_128x32 (cout_pad = round_up(Cout, 128) rows).
 int conv_halo_launch(KArgs a, hipStream_t s) {
     // 256-channel column blocks read two 128-row W tile columns: only when Cout is a multiple of 256
-    if (a.N % 256 == 0 && !getenv("SVR2_HALO_NARROW")) return launch_halo<16, 256>(a, s);
+    if (a.N % 256 == 0) return launch_halo<16, 256>(a, s);
     // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile
-    if (a.N <= 16 && !getenv("SVR2_HALO_NO_N16")) return launch_halo<64, 16>(a, s);
+    if (a.N <= 16) return launch_halo<64, 16>(a, s);
     return launch_halo<32, 128>(a, s);
 }
 

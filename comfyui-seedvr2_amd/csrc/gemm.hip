@@ -404,6 +404,13 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
     }
 }
 
+// Pixel-patch tiling of the halo-resident kernel for a conv (conv_halo.hip picks the same geometry from Cout).
+extern "C" int32_t svr2_conv3d_gn_tiles(int32_t Ho, int32_t Wo, int32_t Cout) {
+    if (Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
+    const int pw = Cout % 256 == 0 ? 16 : (Cout <= 16 ? 64 : 32);
+    return ((Ho + 15) / 16) * ((Wo + pw - 1) / pw);
+}
+
 extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
     const bool tiled = d->w_layout == SVR2_WL_TILED_128x32;
@@ -442,7 +449,9 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
         const bool halo_shape = d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
                                 d->pad_h0 == 1 && d->pad_w0 == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
         SVR2_CHECK(halo_shape, SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_TILED_128x32 needs a 3x3 stride-1 pad-1 conv");
+        a.stats = d->gn_partial;
         return conv_halo_launch(a, (hipStream_t)stream);
     }
+    SVR2_CHECK(d->gn_partial == nullptr, SVR2_E_ARG, "svr2_conv3d: gn_partial needs w_layout SVR2_WL_TILED_128x32");
     return launch<A_CONV, SVR2_EPI_BIAS>(a, (hipStream_t)stream);
 }

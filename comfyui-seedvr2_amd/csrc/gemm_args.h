@@ -21,6 +21,7 @@ struct KArgs {
     const float* gate;
     const bf16* resid;
     const bf16* zero;
+    float* stats;                  // conv_halo.hip: per-tile per-channel (sum, sumsq) of the output, or null
     long long lda, ldc, ldr;
     int M, N, K, nbm, nbn;
     int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;

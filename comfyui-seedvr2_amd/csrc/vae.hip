@@ -48,14 +48,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16* __restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ coef,
-                                                         long long P, int C, int G, int nblk, float eps) {
-    const int f = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ coef,
+                                                          long long P, int C, int G, int nblk, float eps) {
+    __shared__ double red[2][4];
+    const int f = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpg = C / G;
     double s = 0.0, ss = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+    for (int b = tid; b < nblk; b += 256) {
         const float* ps = partial + (((long long)f * nblk + b) * 2) * C + g * cpg;
         for (int c = 0; c < cpg; ++c) {
             s += (double)ps[c];
@@ -67,12 +68,16 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
         s += __shfl_xor(s, o, 64);
         ss += __shfl_xor(ss, o, 64);
     }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double n = (double)P * cpg;
     const double mean = s / n;
     double var = ss / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int c = lane; c < cpg; c += 64) {
+    for (int c = tid; c < cpg; c += 256) {
         const int ch = g * cpg + c;
         const float a = rstd * gamma[ch];
         coef[((long long)f * C + ch) * 2 + 0] = a;
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ coef,
-                                                       bf16* __restrict__ y, long long P, int C, int nblk) {
+                                                       bf16* __restrict__ y, long long P, int C, int nblk,
+                                                       bf16* __restrict__ carry, int f0) {
     const int nvec = C >> 3, ppb = 256 / nvec;
     const int vec = threadIdx.x % nvec, prow = threadIdx.x / nvec;
     if (prow >= ppb) return;
@@ -96,6 +102,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
         b[e] = coef[((long long)f * C + vec * 8 + e) * 2 + 1];
     }
     const long long base = ((long long)f * P) * C + vec * 8;
+    // frames >= f0 are also written to the consumer conv's carry buffer (its last kt - st input frames)
+    bf16* const cdst = (carry && f >= f0) ? carry + ((long long)(f - f0) * P) * C + vec * 8 : nullptr;
     for (long long p = p0 + prow; p < p1; p += ppb) {
         const bf16x8 v = *(const bf16x8*)(x + base + p * C);
         bf16x8 o;
@@ -106,6 +114,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
             o[e] = f2bf(t);
         }
         *(bf16x8*)(y + base + p * C) = o;
+        if (cdst) *(bf16x8*)(cdst + p * C) = o;
     }
 }
 
@@ -280,26 +289,41 @@ extern "C" int svr2_groupnorm_stats(const void* x, int32_t F, int64_t P, int32_t
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, workspace, (long long)P, C,
                        nblk);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, F), dim3(64), 0, s, workspace, gamma, beta, coef, (long long)P, C, G,
-                       nblk, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, F), dim3(256), 0, s, workspace, gamma, beta, coef, (long long)P, C,
+                       G, nblk, eps);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_groupnorm_finalize(const float* partial, int32_t nblk, int32_t F, int64_t P, int32_t C, int32_t G,
+                                       float eps, const float* gamma, const float* beta, float* coef, void* stream) {
+    SVR2_CHECK(partial && gamma && beta && coef, SVR2_E_ARG, "svr2_groupnorm_finalize: null pointer");
+    SVR2_CHECK(F > 0 && F <= 65535 && P > 0 && C > 0 && G > 0 && C % G == 0 && nblk > 0, SVR2_E_SHAPE,
+               "svr2_groupnorm_finalize: unsupported shape F=%d C=%d G=%d nblk=%d", F, C, G, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, F), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, coef,
+                       (long long)P, C, G, nblk, eps);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
 
 extern "C" int svr2_groupnorm_apply(const void* x, const float* coef, void* y, int32_t F, int64_t P, int32_t C,
-                                    int32_t silu, void* stream) {
+                                    int32_t silu, void* carry_out, int32_t carry_frames, void* stream) {
     SVR2_CHECK(x && coef && y, SVR2_E_ARG, "svr2_groupnorm_apply: null pointer");
     SVR2_CHECK(F > 0 && F <= 65535 && P > 0 && C >= 8 && C <= 2048 && C % 8 == 0 && 256 % (C / 8) == 0, SVR2_E_SHAPE,
                "svr2_groupnorm_apply: unsupported shape");
-    SVR2_CHECK(aligned16(x) && aligned16(y), SVR2_E_ALIGN, "svr2_groupnorm_apply: alignment");
+    SVR2_CHECK(aligned16(x) && aligned16(y) && (!carry_out || aligned16(carry_out)), SVR2_E_ALIGN,
+               "svr2_groupnorm_apply: alignment");
+    SVR2_CHECK(!carry_out || (carry_frames > 0 && carry_frames <= F), SVR2_E_SHAPE,
+               "svr2_groupnorm_apply: carry_frames must be in [1, F]");
     const int nblk = gn_blocks(P, C);
+    const int f0 = carry_out ? F - carry_frames : F;
     hipStream_t s = (hipStream_t)stream;
     if (silu)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, coef, (bf16*)y,
-                           (long long)P, C, nblk);
+                           (long long)P, C, nblk, (bf16*)carry_out, f0);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nblk, F), dim3(256), 0, s, (const bf16*)x, coef, (bf16*)y,
-                           (long long)P, C, nblk);
+                           (long long)P, C, nblk, (bf16*)carry_out, f0);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

@@ -48,6 +48,7 @@ class Conv3dDesc(C.Structure):
         ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("zero_page", C.c_void_p),
         ("w_layout", C.c_int32),
+        ("gn_partial", C.c_void_p),
     ]
 
 
@@ -71,6 +72,7 @@ EXPORTS = [
     "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
     "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_txt_mean", "svr2_patch_in",
     "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
+    "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles",
     "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
 ]
 
@@ -242,7 +244,14 @@ def conv_out_size(t, hi, wi, k, s, npad, pad_hw):
     return to, ho, wo
 
 
-def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y, w_layout=WL_ROWS):
+class GnPartial:
+    """Per-tile per-channel (sum, sum of squares) of a conv output: fp32 [F, tiles, 2, C] (svr2_conv3d gn_partial)."""
+
+    def __init__(self, buf: torch.Tensor, tiles: int):
+        self.buf, self.tiles = buf, tiles
+
+
+def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y, w_layout=WL_ROWS, gn_partial=None):
     T, Hi, Wi, Cin = x.shape
     To, Ho, Wo = conv_out_size(T, Hi, Wi, k, s, npad, pad_hw)
     d = Conv3dDesc()
@@ -257,15 +266,17 @@ def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y, w_layout=W
     d.To, d.Ho, d.Wo = To, Ho, Wo
     d.zero_page = zero_page(x.device).data_ptr()
     d.w_layout = w_layout
+    d.gn_partial = gn_partial.data_ptr() if gn_partial is not None else None
     return d, (To, Ho, Wo)
 
 
 def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad: int, pad_hw=(1, 1, 1, 1),
            carry: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
            resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           w_layout: int = WL_ROWS) -> torch.Tensor:
+           w_layout: int = WL_ROWS, gn_stats: bool = False):
     """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w = pad_weight(conv_weight(w5d)) ([cout_pad, kt*kh*kw*Cin]), or
-    conv_weight_tiled(w5d) with w_layout = WL_TILED_128x32."""
+    conv_weight_tiled(w5d) with w_layout = WL_TILED_128x32.  gn_stats (tiled layout only): also return the per-tile
+    GroupNorm partial sums of the output, (out, GnPartial), for groupnorm_silu(..., partial=...)."""
     _bf16c(x, "conv3d.x"); _bf16c(w, "conv3d.w")
     if x.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
         raise HipError("conv3d: x must be contiguous [T,H,W,C]")
@@ -286,9 +297,17 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
     _f32c(bias, "conv3d.bias", cout)
     if resid is not None and (tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
         raise HipError("conv3d: resid must match the output shape")
-    d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out, w_layout)
+    part = None
+    if gn_stats:
+        if w_layout != WL_TILED_128x32:
+            raise HipError("conv3d: gn_stats needs the tiled weight layout")
+        lib().svr2_conv3d_gn_tiles.restype = C.c_int32
+        tiles = int(lib().svr2_conv3d_gn_tiles(C.c_int32(Ho), C.c_int32(Wo), C.c_int32(cout)))
+        part = GnPartial(torch.empty(To, tiles, 2, cout, dtype=torch.float32, device=x.device), tiles)
+    d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out, w_layout,
+                      part.buf if part is not None else None)
     _check(lib().svr2_conv3d(C.byref(d), _stream()), "svr2_conv3d")
-    return out
+    return (out, part) if gn_stats else out
 
 
 def im2col3d(x: torch.Tensor, k, s, *, npad: int, pad_hw, carry: Optional[torch.Tensor], kpad: int) -> torch.Tensor:
@@ -407,26 +426,44 @@ def patch_out_x0(pred: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------- VAE kernels
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                   silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-frame GroupNorm (+SiLU) of a channels-last activation x [F, H, W, C]."""
+                   silu: bool = True, out: Optional[torch.Tensor] = None, partial: Optional[GnPartial] = None,
+                   carry_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-frame GroupNorm (+SiLU) of a channels-last activation x [F, H, W, C].
+    partial: statistics the producing conv already reduced per tile (conv3d(..., gn_stats=True)) - skips the
+    statistics pass over x.  carry_out [k, H, W, C]: also receives the last k output frames (the consumer conv's
+    causal state)."""
     _bf16c(x, "groupnorm.x")
     if x.dim() != 4 or not x.is_contiguous():
         raise HipError("groupnorm: x must be contiguous [F,H,W,C]")
     Fr, H, W, Cc = x.shape
     _f32c(gamma, "groupnorm.gamma", Cc); _f32c(beta, "groupnorm.beta", Cc)
     P = H * W
-    nws = lib().svr2_groupnorm_ws_floats(C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc))
-    if nws <= 0:
-        raise HipError(f"groupnorm: unsupported shape {tuple(x.shape)}")
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     coef = torch.empty(Fr, Cc, 2, dtype=torch.float32, device=x.device)
-    _check(lib().svr2_groupnorm_stats(_p(x), C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc), C.c_int32(groups),
-                                      C.c_float(eps), _p(gamma), _p(beta), _p(ws), _p(coef), _stream()),
-           "svr2_groupnorm_stats")
+    if partial is not None:
+        if tuple(partial.buf.shape) != (Fr, partial.tiles, 2, Cc) or not partial.buf.is_contiguous():
+            raise HipError("groupnorm: partial sums do not match x")
+        _check(lib().svr2_groupnorm_finalize(_p(partial.buf), C.c_int32(partial.tiles), C.c_int32(Fr), C.c_int64(P),
+                                             C.c_int32(Cc), C.c_int32(groups), C.c_float(eps), _p(gamma), _p(beta),
+                                             _p(coef), _stream()), "svr2_groupnorm_finalize")
+    else:
+        nws = lib().svr2_groupnorm_ws_floats(C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc))
+        if nws <= 0:
+            raise HipError(f"groupnorm: unsupported shape {tuple(x.shape)}")
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        _check(lib().svr2_groupnorm_stats(_p(x), C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc), C.c_int32(groups),
+                                          C.c_float(eps), _p(gamma), _p(beta), _p(ws), _p(coef), _stream()),
+               "svr2_groupnorm_stats")
     if out is None:
         out = torch.empty_like(x)
+    nc = 0
+    if carry_out is not None:
+        _bf16c(carry_out, "groupnorm.carry_out")
+        nc = carry_out.shape[0]
+        if carry_out.dim() != 4 or tuple(carry_out.shape[1:]) != (H, W, Cc) or not carry_out.is_contiguous() or nc > Fr:
+            raise HipError("groupnorm: carry_out must be contiguous [k <= F, H, W, C]")
     _check(lib().svr2_groupnorm_apply(_p(x), _p(coef), _p(out), C.c_int32(Fr), C.c_int64(P), C.c_int32(Cc),
-                                      C.c_int32(1 if silu else 0), _stream()), "svr2_groupnorm_apply")
+                                      C.c_int32(1 if silu else 0), _p(carry_out) if carry_out is not None else None,
+                                      C.c_int32(nc), _stream()), "svr2_groupnorm_apply")
     return out
 
 

@@ -52,6 +52,8 @@ class _State:
         self.mem: Dict[str, torch.Tensor] = {}
         self.active = False
         self.last = False   # final chunk: nothing to carry
+        self.stats = None   # (tensor, hip.GnPartial): GroupNorm partial sums the last halo conv wrote for its output
+        self.next_carry: Dict[str, torch.Tensor] = {}   # conv name -> carry its producer (a norm) already wrote
 
 
 class VideoVAEHip:
@@ -120,41 +122,64 @@ class VideoVAEHip:
         else:
             if "w" not in c:
                 self._conv_weight(c, stride, pad_hw)
-            y = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
-                           bias=c["bias"], resid=resid, w_layout=c["layout"])
+            if c["layout"] == hip.WL_TILED_128x32 and c["cout"] % 8 == 0:
+                # halo-resident kernel: its epilogue also reduces the GroupNorm statistics of the output per tile
+                y, part = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
+                                     bias=c["bias"], resid=resid, w_layout=c["layout"], gn_stats=True)
+                st.stats = (y, part)
+            else:
+                y = hip.conv3d(x, c["w"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
+                               bias=c["bias"], resid=resid, w_layout=c["layout"])
         if keep > 0 and not st.last:
             # carry the last `keep` input frames to the next chunk  [ref: causal_inflation_lib.py:266-278].  The old
             # carry is released first (stream-ordered reuse: the conv that reads it is already enqueued).
-            if x.shape[0] >= keep:
-                carry = None
+            carry = None
+            if name in st.next_carry:          # the norm that produced x already stored them (_norm carry_for=)
+                st.mem[name] = st.next_carry.pop(name)
+            elif x.shape[0] >= keep:
                 st.mem[name] = None
                 st.mem[name] = x[x.shape[0] - keep:].clone()
             else:
-                head = carry if carry is not None else x[:1].expand(npad, -1, -1, -1)
+                head = st.mem.get(name) if st.active else None
+                head = head if head is not None else x[:1].expand(npad, -1, -1, -1)
                 st.mem[name] = torch.cat((head, x), dim=0)[-keep:].clone()
         elif keep > 0:
             st.mem.pop(name, None)
+        st.next_carry.pop(name, None)
         return y
 
-    def _norm(self, name: str, x: torch.Tensor, silu: bool = True) -> torch.Tensor:
+    def _norm(self, name: str, x: torch.Tensor, st: _State, silu: bool = True,
+              carry_for: Optional[str] = None) -> torch.Tensor:
+        """GroupNorm (+SiLU).  Uses the statistics the producing conv reduced in its epilogue when x is that conv's
+        output; carry_for = name of the causal conv that consumes the result: its next-chunk state (the last kt-1
+        frames of the result) is written by the same pass instead of being copied out afterwards."""
         g, b = self.norms[name]
-        return hip.groupnorm_silu(x, g, b, self.cfg.norm_groups, self.cfg.eps, silu=silu)
+        part = st.stats[1] if (st.stats is not None and st.stats[0] is x) else None
+        st.stats = None
+        carry_out = None
+        if carry_for is not None and not st.last:
+            keep = self.convs[carry_for]["k"][0] - 1
+            if 0 < keep <= x.shape[0]:
+                carry_out = torch.empty((keep,) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=x.device)
+                st.next_carry[carry_for] = carry_out
+        return hip.groupnorm_silu(x, g, b, self.cfg.norm_groups, self.cfg.eps, silu=silu, partial=part,
+                                  carry_out=carry_out)
 
     def _resnet(self, name: str, x: torch.Tensor, st: _State) -> torch.Tensor:
-        h = self._norm(name + ".norm1", x)
+        h = self._norm(name + ".norm1", x, st, carry_for=name + ".conv1")
         h = self._conv(name + ".conv1", h, st)
-        h = self._norm(name + ".norm2", h)
+        h = self._norm(name + ".norm2", h, st, carry_for=name + ".conv2")
         skip = x
         if (name + ".conv_shortcut") in self.convs:
             skip = self._conv(name + ".conv_shortcut", x, st, pad_hw=(0, 0, 0, 0))
         return self._conv(name + ".conv2", h, st, resid=skip)
 
-    def _mid_attention(self, name: str, x: torch.Tensor) -> torch.Tensor:
+    def _mid_attention(self, name: str, x: torch.Tensor, st: _State) -> torch.Tensor:
         a = self.attn[name]
         T, H, W, Cc = x.shape
         if Cc != 512:
             raise hip.HipError("mid-block attention kernel is built for 512 channels")
-        h = self._norm(name + ".group_norm", x, silu=False).view(T * H * W, Cc)
+        h = self._norm(name + ".group_norm", x, st, silu=False).view(T * H * W, Cc)
         qkv = hip.gemm(h, a["w_qkv"], 3 * Cc, bias=a["b_qkv"])
         o = hip.attn_d512(qkv, T, H * W)
         out = hip.gemm(o, a["w_out"], Cc, bias=a["b_out"], resid=x.view(T * H * W, Cc))
@@ -162,7 +187,7 @@ class VideoVAEHip:
 
     def _mid(self, side: str, x: torch.Tensor, st: _State) -> torch.Tensor:
         x = self._resnet(f"{side}.mid_block.resnets.0", x, st)
-        x = self._mid_attention(f"{side}.mid_block.attentions.0", x)
+        x = self._mid_attention(f"{side}.mid_block.attentions.0", x, st)
         return self._resnet(f"{side}.mid_block.resnets.1", x, st)
 
     def _upsample(self, name: str, x: torch.Tensor, tz: int, st: _State) -> torch.Tensor:
@@ -188,7 +213,7 @@ class VideoVAEHip:
                 h = self._conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", h, st,
                                stride=(2 if tdown else 1, 2, 2), pad_hw=(0, 1, 0, 1))
         h = self._mid("encoder", h, st)
-        h = self._norm("encoder.conv_norm_out", h)
+        h = self._norm("encoder.conv_norm_out", h, st, carry_for="encoder.conv_out")
         return self._conv("encoder.conv_out", h, st)
 
     def _decoder(self, z: torch.Tensor, st: _State) -> torch.Tensor:
@@ -201,7 +226,7 @@ class VideoVAEHip:
                 h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", h, st)
             if i != n - 1:
                 h = self._upsample(f"decoder.up_blocks.{i}.upsamplers.0", h, 2 if i < cfg.temporal_scale_num else 1, st)
-        h = self._norm("decoder.conv_norm_out", h)
+        h = self._norm("decoder.conv_norm_out", h, st, carry_for="decoder.conv_out")
         return self._conv("decoder.conv_out", h, st)
 
     # ------------------------------------------------------------------ public API

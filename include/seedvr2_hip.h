@@ -119,9 +119,13 @@ typedef struct svr2_conv3d_desc {
     int32_t To, Ho, Wo;
     const void* zero_page;
     int32_t w_layout;         /* SVR2_WL_ROWS (0) or SVR2_WL_TILED_128x32 (1) */
+    float* gn_partial;        /* optional (SVR2_WL_TILED_128x32 only): fp32 [To][tiles][2][Cout] per-tile per-channel
+                                 (sum, sum of squares) of the bf16 outputs, tiles = svr2_conv3d_gn_tiles(Ho, Wo, Cout);
+                                 feeds svr2_groupnorm_finalize so the following GroupNorm needs no statistics pass */
 } svr2_conv3d_desc;
 
 int svr2_conv3d(const svr2_conv3d_desc* d, void* stream);
+int32_t svr2_conv3d_gn_tiles(int32_t Ho, int32_t Wo, int32_t Cout);
 
 /* Explicit im2col for the small-Cin causal convs (Cin = 3 or 16): col[M, kpad] with
  * k = ((kt*kh+ky)*kw+kx)*Cin + c, zero padded to kpad (multiple of 64). */
@@ -203,8 +207,14 @@ int svr2_patch_out_x0(const void* pred, int64_t ldp, const void* noise, void* x0
 int64_t svr2_groupnorm_ws_floats(int32_t F, int64_t P, int32_t C);
 int svr2_groupnorm_stats(const void* x, int32_t F, int64_t P, int32_t C, int32_t G, float eps,
                          const float* gamma, const float* beta, float* workspace, float* coef, void* stream);
+/* svr2_groupnorm_finalize: the second launch of svr2_groupnorm_stats alone, on partial sums [F][nblk][2][C] that a
+ *   producer already wrote (svr2_conv3d's gn_partial). */
+int svr2_groupnorm_finalize(const float* partial, int32_t nblk, int32_t F, int64_t P, int32_t C, int32_t G, float eps,
+                            const float* gamma, const float* beta, float* coef, void* stream);
+/* carry_out (optional): the last carry_frames frames of y are also stored to carry_out [carry_frames, P, C] - the
+ *   causal-conv state of the conv that consumes y [ref: causal_inflation_lib.py:266-278], saving a copy pass. */
 int svr2_groupnorm_apply(const void* x, const float* coef, void* y, int32_t F, int64_t P, int32_t C,
-                         int32_t silu, void* stream);
+                         int32_t silu, void* carry_out, int32_t carry_frames, void* stream);
 
 /* ------------------------------------------------------------------ VAE: mid-block spatial attention
  * Single-head attention with head dim 512 over the P = h*w tokens of every latent frame

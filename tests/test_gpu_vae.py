@@ -35,6 +35,31 @@ def test_groupnorm_silu(pkg, gpu, Fr, H, W, C, silu):
     assert_close(out, ref.permute(0, 2, 3, 1), "groupnorm_silu")
 
 
+@pytest.mark.parametrize("T,H,W,Cin,Cout", [(3, 20, 37, 64, 128), (2, 33, 18, 64, 256), (2, 16, 70, 32, 64)])
+def test_conv_epilogue_groupnorm_statistics_and_carry(pkg, gpu, T, H, W, Cin, Cout):
+    """The halo conv's epilogue reduces the GroupNorm statistics of its own output per tile; folded by
+    svr2_groupnorm_finalize they must equal the sums of the stored bf16 output (fp32 partials, fp64 fold:
+    1e-5 relative), the fused norm must equal the two-pass norm, and carry_out must be the last frames bit for bit."""
+    hip = pkg.hip
+    x = rnd(T, H, W, Cin, seed=5)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=6, scale=1 / math.sqrt(27 * Cin))
+    b = rnd(Cout, seed=7)
+    res = rnd(T, H, W, Cout, seed=8)
+    y, part = hip.conv3d(dev_bf16(x, gpu), hip.conv_weight_tiled(w.to(gpu)), Cout, (3, 3, 3), npad=2, bias=b.to(gpu),
+                         resid=dev_bf16(res, gpu), w_layout=hip.WL_TILED_128x32, gn_stats=True)
+    yf = y.float()
+    sums = part.buf.double().sum(dim=1).cpu()                       # [T, 2, Cout]
+    want = torch.stack((yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))), dim=1).double().cpu()
+    assert ((sums - want).abs() <= 1e-5 * want.abs() + 1e-3).all()
+    g, be = (rnd(Cout, seed=9) * 0.1 + 1).to(gpu), (rnd(Cout, seed=10) * 0.1).to(gpu)
+    two_pass = hip.groupnorm_silu(y, g, be, 32, 1e-6)
+    carry = torch.empty(2, H, W, Cout, dtype=torch.bfloat16, device=gpu)
+    fused = hip.groupnorm_silu(y, g, be, 32, 1e-6, partial=part, carry_out=carry)
+    assert (fused.float() - two_pass.float()).abs().max().item() <= 2e-2    # one bf16 ulp at |v| ~ 4
+    assert (fused.float() - two_pass.float()).abs().mean().item() <= 1e-4
+    assert torch.equal(carry, fused[T - 2:])
+
+
 @pytest.mark.parametrize("frames,P", [(2, 200), (1, 4096), (3, 129)])
 def test_attn_d512(pkg, gpu, frames, P):
     qkv = rnd(frames * P, 1536, seed=4)
