@@ -185,7 +185,22 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         if (++kx == 3) { kx = 0; ++sl; hb ^= 1; }
     }
 
-    // ---- epilogue: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8 channels
+    // ---- epilogue: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8 channels.
+    //      The residual chunks this thread will add are requested first, so that their HBM latency runs under the
+    //      accumulator -> LDS round trip instead of once per store (measured: resid convs were 6 % slower).
+    constexpr int EIT = G::BM * (BN / 8) / G::NT;      // 16-byte chunks per thread (16, or 4 for BN = 16)
+    bf16x8 rres[EIT];
+    if (a.resid) {
+#pragma unroll
+        for (int k = 0; k < EIT; ++k) {
+            const int c = tid + k * G::NT;
+            const int row = c / (BN / 8), cc = c % (BN / 8);
+            const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
+            const bool ok = y < a.cg.Ho && x < a.cg.Wo && n < a.N;
+            const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
+            rres[k] = ok ? *(const bf16x8*)(a.resid + m * a.ldr + n) : bf16x8{};
+        }
+    }
     asm volatile("s_barrier" ::: "memory");
     {
         f32x4 bv[JN];
@@ -215,7 +230,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
     float st_s[8], st_q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
-    for (int c = tid; c < G::BM * (BN / 8); c += G::NT) {
+#pragma unroll
+    for (int k = 0; k < EIT; ++k) {
+        const int c = tid + k * G::NT;
         const int row = c / (BN / 8), cc = c % (BN / 8);
         const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
         if (y >= a.cg.Ho || x >= a.cg.Wo || n >= a.N) continue;
@@ -225,9 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = bf2f(tv[e]);
         if (a.resid) {
-            const bf16x8 rv = *(const bf16x8*)(a.resid + m * a.ldr + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(rres[k][e]);
         }
         const long long dst = m * a.ldc + n;
         bf16x8 o;

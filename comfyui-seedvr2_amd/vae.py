@@ -139,6 +139,8 @@ class VideoVAEHip:
             elif x.shape[0] >= keep:
                 st.mem[name] = None
                 st.mem[name] = x[x.shape[0] - keep:].clone()
+            elif not st.active and x.shape[0] == 1:
+                st.mem[name] = x.expand(keep, -1, -1, -1).contiguous()   # first chunk of one frame: replicas of it
             else:
                 head = st.mem.get(name) if st.active else None
                 head = head if head is not None else x[:1].expand(npad, -1, -1, -1)

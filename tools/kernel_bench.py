@@ -52,7 +52,7 @@ def bench_gemm(M, N, K, epi="bias"):
     print(f"gemm[{epi}] M={M} N={N} K={K}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s", flush=True)
 
 
-def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False):
+def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False, resid=False):
     x = rb(T, H, W, Cin)
     if tiled:
         w = hip.conv_weight_tiled(rb(Cout, Cin, *k, scale=0.02))
@@ -60,11 +60,12 @@ def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False):
         w = hip.pad_weight(rb(Cout, k[0] * k[1] * k[2] * Cin, scale=0.02))
     b = torch.zeros(Cout, device=dev)
     out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
-    fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out,
+    res = rb(T, H, W, Cout) if resid else None
+    fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out, resid=res,
                             w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS)
     t = timeit(fn)
     fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
-    tag = "halo/tiled" if tiled else "tap-staged"
+    tag = ("halo/tiled" if tiled else "tap-staged") + ("+resid" if resid else "")
     print(f"conv3d[{tag}] T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
@@ -112,6 +113,16 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "gemmsmall" in which:   # the memory-bound / narrow GEMMs of the VAE (run once per SVR2_GEMM_V value)
+        print("SVR2_GEMM_V =", os.environ.get("SVR2_GEMM_V", "2"))
+        bench_gemm(33177600, 128, 128)        # encoder conv_in after im2col, 4 frames at 4K
+        bench_gemm(777600, 1536, 512)         # mid-block attention qkv, 6 latent frames
+        bench_gemm(777600, 512, 512)
+        bench_gemm(8294400, 512, 256)
+    if "haloresid" in which:
+        for shp in ((4, 2160, 3840, 128, 128), (4, 1080, 1920, 256, 256), (2, 540, 960, 512, 512)):
+            bench_conv(*shp, tiled=True)
+            bench_conv(*shp, tiled=True, resid=True)
     if "halopmc" in which:   # few launches of the three dominant halo-conv shapes for counter collection
         bench_conv(4, 2160, 3840, 128, 128, tiled=True)
         bench_conv(4, 1080, 1920, 256, 256, tiled=True)
