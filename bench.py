@@ -293,7 +293,7 @@ def main():
         if args.workload == "cfg3" and os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
-                    traffic = json.load(fh)["kernels"]["conv3d (A_CONV kernels of gemm.hip + gemm2.hip)"]["hbm_bytes_per_launch"]
+                    traffic = json.load(fh)["conv3d_all"]["hbm_bytes_per_launch"]   # all conv launches of a step
             except Exception:
                 traffic = None
         result = {
