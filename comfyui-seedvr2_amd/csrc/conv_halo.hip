@@ -54,6 +54,111 @@ template <int PW, int BN> struct GeoH {
     static_assert((BM / 128) * NWN == 8 && LDS <= 160 * 1024, "geometry");
 };
 
+// Epilogue shared by both kernels: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8
+// channels (+ residual, + GroupNorm partial sums).  Call with every wave past its last LDS read of the K loop.
+template <int PW, int BN>
+__device__ __forceinline__ void halo_epilogue(const KArgs& a, char* smem, f32x4 (&acc)[8][GeoH<PW, BN>::JN], int tid, int t,
+                                              int per_frame, int rem, int y0, int x0, int n0, int wn, int wpy0,
+                                              int wpx0, int pix, int fq) {
+    using G = GeoH<PW, BN>;
+    constexpr int JN = G::JN;
+    //      The residual chunks this thread will add are requested first, so that their HBM latency runs under the
+    //      accumulator -> LDS round trip instead of once per store (measured: resid convs were 6 % slower).
+    constexpr int EIT = G::BM * (BN / 8) / G::NT;      // 16-byte chunks per thread (16, or 4 for BN = 16)
+    bf16x8 rres[EIT];
+    if (a.resid) {
+#pragma unroll
+        for (int k = 0; k < EIT; ++k) {
+            const int c = tid + k * G::NT;
+            const int row = c / (BN / 8), cc = c % (BN / 8);
+            const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
+            const bool ok = y < a.cg.Ho && x < a.cg.Wo && n < a.N;
+            const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
+            rres[k] = ok ? *(const bf16x8*)(a.resid + m * a.ldr + n) : bf16x8{};
+        }
+    }
+    asm volatile("s_barrier" ::: "memory");
+    {
+        f32x4 bv[JN];
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + wn * 64 + j * 16 + 4 * fq;
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[j][r] = (n + r < a.N) ? a.bias[n + r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r] + bv[j][r]);
+                const int prow = (wpy0 + i) * PW + wpx0 + pix;
+                *(bf16x4*)(smem + prow * G::EPI_LD + (wn * 64 + j * 16 + 4 * fq) * 2) = o;
+            }
+    }
+    __syncthreads();
+    // optional GroupNorm statistics of the tile (of the rounded bf16 outputs, the values the next norm reads): a
+    // thread always handles the same 8 channels (BN/8 divides the block size), so it keeps 8 (sum, sumsq) pairs
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < EIT; ++k) {
+        const int c = tid + k * G::NT;
+        const int row = c / (BN / 8), cc = c % (BN / 8);
+        const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
+        if (y >= a.cg.Ho || x >= a.cg.Wo || n >= a.N) continue;
+        const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
+        const bf16x8 tv = *(const bf16x8*)(smem + row * G::EPI_LD + cc * 16);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(tv[e]);
+        if (a.resid) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(rres[k][e]);
+        }
+        const long long dst = m * a.ldc + n;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        if (n + 8 <= a.N) {
+            *(bf16x8*)(a.C + dst) = o;
+        } else {
+            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = o[e];
+        }
+        if (a.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r = bf2f(o[e]);
+                st_s[e] += r;
+                st_q[e] += r * r;
+            }
+        }
+    }
+    if (a.stats) {   // partial[frame][tile][2][N], folded over tiles by svr2_groupnorm_finalize (fixed order: deterministic)
+        constexpr int NV = BN / 8, RPT = G::NT / NV;
+        __syncthreads();                                   // the epilogue tile has been read
+        float* red = (float*)smem;                         // [NT][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid * 16 + e] = st_s[e];
+            red[tid * 16 + 8 + e] = st_q[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < NV * 16; i += G::NT) {
+            const int v = i >> 4, e = i & 15;
+            float acc2 = 0.f;
+            for (int r = 0; r < RPT; ++r) acc2 += red[(r * NV + v) * 16 + e];
+            const int n = n0 + v * 8 + (e & 7);
+            if (n < a.N) a.stats[(((long long)t * per_frame + rem) * 2 + (e >> 3)) * a.N + n] = acc2;
+        }
+    }
+}
+
 template <int PW, int BN>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
@@ -185,110 +290,129 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         if (++kx == 3) { kx = 0; ++sl; hb ^= 1; }
     }
 
-    // ---- epilogue: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8 channels.
-    //      The residual chunks this thread will add are requested first, so that their HBM latency runs under the
-    //      accumulator -> LDS round trip instead of once per store (measured: resid convs were 6 % slower).
-    constexpr int EIT = G::BM * (BN / 8) / G::NT;      // 16-byte chunks per thread (16, or 4 for BN = 16)
-    bf16x8 rres[EIT];
-    if (a.resid) {
-#pragma unroll
-        for (int k = 0; k < EIT; ++k) {
-            const int c = tid + k * G::NT;
-            const int row = c / (BN / 8), cc = c % (BN / 8);
-            const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
-            const bool ok = y < a.cg.Ho && x < a.cg.Wo && n < a.N;
-            const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
-            rres[k] = ok ? *(const bf16x8*)(a.resid + m * a.ldr + n) : bf16x8{};
-        }
-    }
-    asm volatile("s_barrier" ::: "memory");
-    {
-        f32x4 bv[JN];
-#pragma unroll
-        for (int j = 0; j < JN; ++j) {
-            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + wn * 64 + j * 16 + 4 * fq;
-            if (a.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bv[j][r] = (n + r < a.N) ? a.bias[n + r] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < JN; ++j) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r] + bv[j][r]);
-                const int prow = (wpy0 + i) * PW + wpx0 + pix;
-                *(bf16x4*)(smem + prow * G::EPI_LD + (wn * 64 + j * 16 + 4 * fq) * 2) = o;
-            }
-    }
-    __syncthreads();
-    // optional GroupNorm statistics of the tile (of the rounded bf16 outputs, the values the next norm reads): a
-    // thread always handles the same 8 channels (BN/8 divides the block size), so it keeps 8 (sum, sumsq) pairs
-    float st_s[8], st_q[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
-#pragma unroll
-    for (int k = 0; k < EIT; ++k) {
-        const int c = tid + k * G::NT;
-        const int row = c / (BN / 8), cc = c % (BN / 8);
-        const int y = y0 + row / PW, x = x0 + row % PW, n = n0 + cc * 8;
-        if (y >= a.cg.Ho || x >= a.cg.Wo || n >= a.N) continue;
-        const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
-        const bf16x8 tv = *(const bf16x8*)(smem + row * G::EPI_LD + cc * 16);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(tv[e]);
-        if (a.resid) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(rres[k][e]);
-        }
-        const long long dst = m * a.ldc + n;
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-        if (n + 8 <= a.N) {
-            *(bf16x8*)(a.C + dst) = o;
-        } else {
-            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = o[e];
-        }
-        if (a.stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float r = bf2f(o[e]);
-                st_s[e] += r;
-                st_q[e] += r * r;
-            }
-        }
-    }
-    if (a.stats) {   // partial[frame][tile][2][N], folded over tiles by svr2_groupnorm_finalize (fixed order: deterministic)
-        constexpr int NV = BN / 8, RPT = G::NT / NV;
-        __syncthreads();                                   // the epilogue tile has been read
-        float* red = (float*)smem;                         // [NT][16]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[tid * 16 + e] = st_s[e];
-            red[tid * 16 + 8 + e] = st_q[e];
-        }
-        __syncthreads();
-        for (int i = tid; i < NV * 16; i += G::NT) {
-            const int v = i >> 4, e = i & 15;
-            float acc2 = 0.f;
-            for (int r = 0; r < RPT; ++r) acc2 += red[(r * NV + v) * 16 + e];
-            const int n = n0 + v * 8 + (e & 7);
-            if (n < a.N) a.stats[(((long long)t * per_frame + rem) * 2 + (e >> 3)) * a.N + n] = acc2;
-        }
-    }
+    halo_epilogue<PW, BN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn, wpy0, wpx0, pix, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// W-through-registers variant (A/B candidate, SVR2_HALO_WR=1).  The W fragments never touch LDS: every wave loads them
+// straight from the tiled global layout into registers (one fully coalesced KiB per fragment), two taps ahead of
+// their use.  Only the halo goes through LDS, so the workgroup synchronises once per channel slice (nine taps, 288
+// MFMAs per wave) and the LDS-DMA stream shrinks from 37-55 KiB to 7-13 KiB per super-step.  A halo wave's W loads
+// queue behind its halo DMAs (vmcnt retires in order); its SIMD partner issues no halo DMA and meets it only at the
+// slice barrier, so it keeps the MFMA pipe fed meanwhile.  The nine taps of a slice are straight-line code so that the
+// compiler's counted vmcnt waits stay exact (a branch between a load and its use makes it fall back to vmcnt(0)).
 template <int PW, int BN>
+__global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
+    using G = GeoH<PW, BN>;
+    constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK, JN = G::JN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo0 = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool hrole = wave >= 4;
+    int tm, tn;
+    tile_coords(a, tm, tn);
+    const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
+    const int t = tm / per_frame, rem = tm - t * per_frame;
+    const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
+    const int y0 = ty * G::PH, x0 = tx * PW, n0 = tn * BN;
+    const int Cin = a.cg.Cin, Wi = a.cg.Wi, Hi = a.cg.Hi;
+    const int ncs = Cin / BK, nsl = a.cg.kt * ncs, ntap = nsl * 9;
+
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const char* zsrc = (const char*)a.zero + lslot * 16;
+    const long long frame_bytes = (long long)Hi * Wi * Cin * 2;
+    const long long org = (((long long)(y0 - 1) * Wi + (x0 - 1)) * Cin) * 2;
+    auto slice_base = [&](int tap_t, int cs) -> const char* {
+        const int it = t + tap_t;
+        const bool head = it < a.cg.npad;
+        const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
+        const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+        return base + fidx * frame_bytes + org + cs * (BK * 2);
+    };
+    auto issue_halo = [&](const char* sb, char* hbuf) {      // waves 4-7: pieces q = u*4 + (wave - 4)
+        for (int u = 0; u < G::HPW; ++u) {
+            const int q = u * 4 + (wave - 4);
+            if (q >= G::NHI) break;
+            const int r = q * RPI + lrow;
+            const int hy = r / HP, hx = r - hy * HP;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = (r < G::HROWS) & ((unsigned)iy < (unsigned)Hi) & ((unsigned)ix < (unsigned)Wi);
+            const int off = ((hy * Wi + hx) * Cin) * 2 + ((lslot ^ ((hx >> 2) & 3)) << 4);
+            glds16(ok ? sb + off : zsrc, hbuf + q * 1024);
+        }
+    };
+
+    constexpr int WPX = PW / 16;
+    const int wm = wave / G::NWN, wn = wave % G::NWN;
+    const int wpy0 = (wm / WPX) * 8, wpx0 = (wm % WPX) * 16;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int pix = frow < 4 ? 2 * frow : (frow < 12 ? 2 * frow - 7 : 2 * frow - 16);   // pi(frow)
+    const int hxl = wpx0 + pix;
+    const int rbase = wpy0 * HP + hxl;
+    // this wave's fragments of tap u are the KiB blocks [cch%128/16 + jn] of the u-th 8-KiB tap tile of 128-channel
+    // tile column cch/128 (cch = the wave's first channel); lane (frow, fq) reads row frow, chunk fq, which the
+    // LDS-image order of the tile keeps at slot fq ^ f(frow)
+    const int cch = n0 + wn * 64;
+    const char* wfk = (const char*)a.W + (long long)(cch / 128) * ntap * 8192 + (cch % 128) * ROWB;        // uniform
+    const unsigned wfl = frow * ROWB + ((fq ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3)) << 4);              // per lane
+    f32x4 acc[8][JN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 bw[3][JN];
+    auto load_w = [&](int slot, int u) {
+        const char* p = wfk + (long long)(u < ntap ? u : ntap - 1) * 8192;    // past the end: a harmless reload
+#pragma unroll
+        for (int jn = 0; jn < JN; ++jn) bw[slot][jn] = *(const bf16x8*)(p + jn * 1024 + wfl);
+    };
+
+    if (hrole) issue_halo(slice_base(0, 0), halo0);
+    load_w(0, 0);
+    load_w(1, 1);
+
+    int tap_t = 0, cs = 0, hb = 0;
+    for (int sl = 0; sl < nsl; ++sl) {
+        // the halo of this slice has landed for every wave and every wave is done reading the other buffer
+        if (hrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (hrole && sl + 1 < nsl) {
+            if (++cs == ncs) { cs = 0; ++tap_t; }
+            issue_halo(slice_base(tap_t, cs), halo0 + (hb ^ 1) * G::HALO_BYTES);
+        }
+        const char* hcur = halo0 + hb * G::HALO_BYTES;
+        const int u0 = sl * 9;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const char* sA = hcur + (rbase + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4);
+            bf16x8 af[10];
+#pragma unroll
+            for (int r = 0; r < 10; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int tapi = kx * 3 + ky;                  // tap index inside the slice; ring slot = tapi % 3 = ky
+                load_w((ky + 2) % 3, u0 + tapi + 2);           // two taps ahead, into the slot freed by the last tap
+                __builtin_amdgcn_sched_barrier(0);             // or the scheduler sinks the loads next to their use
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < JN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ky][jn], af[i + ky], acc[i][jn], 0, 0, 0);
+            }
+        }
+        hb ^= 1;
+    }
+    asm volatile("s_barrier" ::: "memory");
+    halo_epilogue<PW, BN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn, wpy0, wpx0, pix, fq);
+}
+
+template <int PW, int BN, bool WR>
 int launch_halo(KArgs a, hipStream_t s) {
     using G = GeoH<PW, BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<PW, BN>,
+        hipError_t e = hipFuncSetAttribute(WR ? (const void*)conv_halo_wr_kernel<PW, BN> : (const void*)conv_halo_kernel<PW, BN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", G::LDS);
         attr_set = true;
@@ -298,7 +422,8 @@ int launch_halo(KArgs a, hipStream_t s) {
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
     a.nbm = a.cg.To * a.cg.tiles_x * a.cg.tiles_y;
     a.nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    if (WR) hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
@@ -308,11 +433,16 @@ int launch_halo(KArgs a, hipStream_t s) {
 // Shape contract (checked by the caller, gemm.hip): kh = kw = 3, stride 1, zero padding 1 on every spatial side
 // (Ho = Hi, Wo = Wi), any kt, Cin % 32 == 0, W in SVR2_WL_TILED_128x32 (cout_pad = round_up(Cout, 128) rows).
 int conv_halo_launch(KArgs a, hipStream_t s) {
+    // SVR2_HALO_WR: bit 0 = W through registers for the 256-channel geometry, bit 1 = for the 128-channel geometry
+    // (default 1; 0 = both through LDS).  Measured (profiles/r01_kernel_bench_halo_wr.log): +5-6 % for the
+    // 256-channel geometry, +1 % (kernel) / 0 % (whole step) for the 128-channel one, whose W is shared by four waves.
+    const char* e = getenv("SVR2_HALO_WR");
+    const int wr = e ? atoi(e) : 1;
     // 256-channel column blocks read two 128-row W tile columns: only when Cout is a multiple of 256
-    if (a.N % 256 == 0) return launch_halo<16, 256>(a, s);
+    if (a.N % 256 == 0) return (wr & 1) ? launch_halo<16, 256, true>(a, s) : launch_halo<16, 256, false>(a, s);
     // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile
-    if (a.N <= 16) return launch_halo<64, 16>(a, s);
-    return launch_halo<32, 128>(a, s);
+    if (a.N <= 16) return launch_halo<64, 16, false>(a, s);
+    return (wr & 2) ? launch_halo<32, 128, true>(a, s) : launch_halo<32, 128, false>(a, s);
 }
 
 }  // namespace svr2

@@ -137,11 +137,13 @@ HALO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("wr", ["0", "3"])
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_conv3d_halo_resident(pkg, gpu, case):
+def test_conv3d_halo_resident(pkg, gpu, case, wr, monkeypatch):
     """conv_halo.hip (halo kept in LDS, nine shifted reads, SVR2_WL_TILED_128x32 weights): both geometries, ragged
     edges, carry, resid; also against the tap-staged kernel on the same inputs."""
     hip = pkg.hip
+    monkeypatch.setenv("SVR2_HALO_WR", wr)   # W fragments through LDS (0) or straight into registers (1)
     T, H, W, Cin, Cout, kt, with_carry, with_res = case
     k, s, npad, pad_hw = (kt, 3, 3), (1, 1, 1), kt - 1, (1, 1, 1, 1)
     x = rnd(T, H, W, Cin, seed=25)
