@@ -35,6 +35,8 @@
 namespace svr2 {
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
 template <int PW, int BN> struct GeoH {
     static constexpr int PH = 16, BM = PH * PW, HP = PW + 2, HROWS = (PH + 2) * HP;
     static constexpr int BK = 32, ROWB = 64, RPI = 16;                  // 64-byte LDS rows, 16 rows per DMA piece
@@ -56,12 +58,11 @@ template <int PW, int BN> struct GeoH {
 
 // Epilogue shared by both kernels: (acc + bias) -> bf16 tile in LDS (tile row = patch pixel py*PW + px) -> rows of 8
 // channels (+ residual, + GroupNorm partial sums).  Call with every wave past its last LDS read of the K loop.
-template <int PW, int BN>
-__device__ __forceinline__ void halo_epilogue(const KArgs& a, char* smem, f32x4 (&acc)[8][GeoH<PW, BN>::JN], int tid, int t,
-                                              int per_frame, int rem, int y0, int x0, int n0, int wn, int wpy0,
+template <int PW, int BN, int MI, int JN>
+__device__ __forceinline__ void halo_epilogue(const KArgs& a, char* smem, f32x4 (&acc)[MI][JN], int tid, int t,
+                                              int per_frame, int rem, int y0, int x0, int n0, int cb, int wpy0,
                                               int wpx0, int pix, int fq) {
     using G = GeoH<PW, BN>;
-    constexpr int JN = G::JN;
     //      The residual chunks this thread will add are requested first, so that their HBM latency runs under the
     //      accumulator -> LDS round trip instead of once per store (measured: resid convs were 6 % slower).
     constexpr int EIT = G::BM * (BN / 8) / G::NT;      // 16-byte chunks per thread (16, or 4 for BN = 16)
@@ -83,21 +84,21 @@ __device__ __forceinline__ void halo_epilogue(const KArgs& a, char* smem, f32x4 
 #pragma unroll
         for (int j = 0; j < JN; ++j) {
             bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + wn * 64 + j * 16 + 4 * fq;
+            const int n = n0 + cb + j * 16 + 4 * fq;
             if (a.bias) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[j][r] = (n + r < a.N) ? a.bias[n + r] : 0.f;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < JN; ++j) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r] + bv[j][r]);
                 const int prow = (wpy0 + i) * PW + wpx0 + pix;
-                *(bf16x4*)(smem + prow * G::EPI_LD + (wn * 64 + j * 16 + 4 * fq) * 2) = o;
+                *(bf16x4*)(smem + prow * G::EPI_LD + (cb + j * 16 + 4 * fq) * 2) = o;
             }
     }
     __syncthreads();
@@ -290,21 +291,28 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         if (++kx == 3) { kx = 0; ++sl; hb ^= 1; }
     }
 
-    halo_epilogue<PW, BN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn, wpy0, wpx0, pix, fq);
+    halo_epilogue<PW, BN, 8, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * 64, wpy0, wpx0, pix, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// W-through-registers variant (A/B candidate, SVR2_HALO_WR=1).  The W fragments never touch LDS: every wave loads them
-// straight from the tiled global layout into registers (one fully coalesced KiB per fragment), two taps ahead of
-// their use.  Only the halo goes through LDS, so the workgroup synchronises once per channel slice (nine taps, 288
-// MFMAs per wave) and the LDS-DMA stream shrinks from 37-55 KiB to 7-13 KiB per super-step.  A halo wave's W loads
-// queue behind its halo DMAs (vmcnt retires in order); its SIMD partner issues no halo DMA and meets it only at the
-// slice barrier, so it keeps the MFMA pipe fed meanwhile.  The nine taps of a slice are straight-line code so that the
-// compiler's counted vmcnt waits stay exact (a branch between a load and its use makes it fall back to vmcnt(0)).
+// W-through-registers kernel.  The W fragments never touch LDS: every wave loads them straight from the tiled global
+// layout into registers (one fully coalesced KiB per fragment), two taps ahead of their use.  Only the halo goes
+// through LDS, so the workgroup synchronises once per channel slice (nine taps, 288 MFMAs per wave) and the LDS-DMA
+// stream that the MFMA pipe was measured to wait for shrinks from 37-55 KiB to 7-13 KiB per super-step.
+//   * Wave tile = one 16 x 16 pixel block x 32 channels (16 x 2 MFMA 16x16x32): waves are laid out (PW/16) x (BN/32),
+//     so the 256-channel geometry loads every W fragment exactly once per workgroup (the texture-data return path was
+//     93 % busy with 128 x 64 wave tiles, which load each fragment twice) and a wave holds the 18 activation fragments
+//     of a kx column (all halo lines of its block; LDS reads are cheap now that W is gone from LDS).
+//   * A halo wave's W loads queue behind its halo DMAs (vmcnt retires in order); its SIMD partner issues no halo DMA
+//     and meets it only at the slice barrier, so it keeps the MFMA pipe fed meanwhile.
+//   * The nine taps of a slice are straight-line code so that the compiler's counted vmcnt waits stay exact (a branch
+//     between a load and its use makes it fall back to vmcnt(0)); sched_barrier pins each load two taps before its use.
 template <int PW, int BN>
 __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
-    constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK, JN = G::JN;
+    constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK;
+    constexpr int WPX = PW / 16, NWN = 8 / WPX, CPW = BN / NWN, JN = CPW / 16, MI = 16;   // CPW = 32 channels per wave
+    static_assert(CPW == 32 && JN == 2, "wave tile is 256 pixels x 32 channels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo0 = smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -331,10 +339,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         return base + fidx * frame_bytes + org + cs * (BK * 2);
     };
     auto issue_halo = [&](const char* sb, char* hbuf) {      // waves 4-7: pieces q = u*4 + (wave - 4)
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));   // recompute the piece addresses per call: hoisted, they cost 2 VGPRs per piece
         for (int u = 0; u < G::HPW; ++u) {
             const int q = u * 4 + (wave - 4);
             if (q >= G::NHI) break;
-            const int r = q * RPI + lrow;
+            const int r = q * RPI + lr;
             const int hy = r / HP, hx = r - hy * HP;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
             const bool ok = (r < G::HROWS) & ((unsigned)iy < (unsigned)Hi) & ((unsigned)ix < (unsigned)Wi);
@@ -343,29 +353,32 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         }
     };
 
-    constexpr int WPX = PW / 16;
-    const int wm = wave / G::NWN, wn = wave % G::NWN;
-    const int wpy0 = (wm / WPX) * 8, wpx0 = (wm % WPX) * 16;
+    const int wm = wave / NWN, wn = wave % NWN;    // x block of the patch, 32-channel column
+    const int wpx0 = wm * 16;
     const int frow = lane & 15, fq = lane >> 4;
     const int pix = frow < 4 ? 2 * frow : (frow < 12 ? 2 * frow - 7 : 2 * frow - 16);   // pi(frow)
-    const int hxl = wpx0 + pix;
-    const int rbase = wpy0 * HP + hxl;
+    const int hxl = wpx0 + pix;                    // halo x of this lane's pixel under kx = 0; halo row of patch row 0
     // this wave's fragments of tap u are the KiB blocks [cch%128/16 + jn] of the u-th 8-KiB tap tile of 128-channel
     // tile column cch/128 (cch = the wave's first channel); lane (frow, fq) reads row frow, chunk fq, which the
     // LDS-image order of the tile keeps at slot fq ^ f(frow)
-    const int cch = n0 + wn * 64;
+    const int cch = n0 + wn * CPW;
     const char* wfk = (const char*)a.W + (long long)(cch / 128) * ntap * 8192 + (cch % 128) * ROWB;        // uniform
     const unsigned wfl = frow * ROWB + ((fq ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3)) << 4);              // per lane
-    f32x4 acc[8][JN];
+    f32x4 acc[MI][JN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 bw[3][JN];
+    // buffer loads: resource (this wave's tile column) and tap offset in SGPRs, one VGPR of per-lane offset
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wfk, 0, 0x7fffffff, 0x00020000);
     auto load_w = [&](int slot, int u) {
-        const char* p = wfk + (long long)(u < ntap ? u : ntap - 1) * 8192;    // past the end: a harmless reload
+        const int so = (u < ntap ? u : ntap - 1) * 8192;                      // past the end: a harmless reload
 #pragma unroll
-        for (int jn = 0; jn < JN; ++jn) bw[slot][jn] = *(const bf16x8*)(p + jn * 1024 + wfl);
+        for (int jn = 0; jn < JN; ++jn) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wfl, so + jn * 1024, 0);
+            bw[slot][jn] = __builtin_bit_cast(bf16x8, v);
+        }
     };
 
     if (hrole) issue_halo(slice_base(0, 0), halo0);
@@ -385,17 +398,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         const int u0 = sl * 9;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const char* sA = hcur + (rbase + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4);
-            bf16x8 af[10];
+            const char* sA = hcur + (hxl + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4);
+            bf16x8 af[MI + 2];                                  // the 18 halo lines of the block, shifted by kx
 #pragma unroll
-            for (int r = 0; r < 10; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
+            for (int r = 0; r < MI + 2; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int tapi = kx * 3 + ky;                  // tap index inside the slice; ring slot = tapi % 3 = ky
                 load_w((ky + 2) % 3, u0 + tapi + 2);           // two taps ahead, into the slot freed by the last tap
                 __builtin_amdgcn_sched_barrier(0);             // or the scheduler sinks the loads next to their use
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < JN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ky][jn], af[i + ky], acc[i][jn], 0, 0, 0);
@@ -404,16 +417,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         hb ^= 1;
     }
     asm volatile("s_barrier" ::: "memory");
-    halo_epilogue<PW, BN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn, wpy0, wpx0, pix, fq);
+    halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
 }
 
 template <int PW, int BN, bool WR>
 int launch_halo(KArgs a, hipStream_t s) {
     using G = GeoH<PW, BN>;
+    const void* fn;
+    if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN>;
+    else fn = (const void*)conv_halo_kernel<PW, BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(WR ? (const void*)conv_halo_wr_kernel<PW, BN> : (const void*)conv_halo_kernel<PW, BN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", G::LDS);
         attr_set = true;
     }
@@ -422,7 +437,7 @@ int launch_halo(KArgs a, hipStream_t s) {
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
     a.nbm = a.cg.To * a.cg.tiles_x * a.cg.tiles_y;
     a.nbn = (a.N + BN - 1) / BN;
-    if (WR) hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    if constexpr (WR) hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
     else hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
@@ -433,11 +448,11 @@ int launch_halo(KArgs a, hipStream_t s) {
 // Shape contract (checked by the caller, gemm.hip): kh = kw = 3, stride 1, zero padding 1 on every spatial side
 // (Ho = Hi, Wo = Wi), any kt, Cin % 32 == 0, W in SVR2_WL_TILED_128x32 (cout_pad = round_up(Cout, 128) rows).
 int conv_halo_launch(KArgs a, hipStream_t s) {
-    // SVR2_HALO_WR: bit 0 = W through registers for the 256-channel geometry, bit 1 = for the 128-channel geometry
-    // (default 1; 0 = both through LDS).  Measured (profiles/r01_kernel_bench_halo_wr.log): +5-6 % for the
-    // 256-channel geometry, +1 % (kernel) / 0 % (whole step) for the 128-channel one, whose W is shared by four waves.
+    // SVR2_HALO_WR: bit 0 = W through registers (conv_halo_wr_kernel) for the 256-channel geometry, bit 1 = for the
+    // 128-channel geometry (default 3; 0 = both through LDS).  Measured, same box (profiles/r01_kernel_bench_halo_wr.log):
+    // 1438 -> 1603, 1510 -> 1656 TFLOP/s (256-channel blocks), 1393 -> 1448 (128-channel blocks).
     const char* e = getenv("SVR2_HALO_WR");
-    const int wr = e ? atoi(e) : 1;
+    const int wr = e ? atoi(e) : 3;
     // 256-channel column blocks read two 128-row W tile columns: only when Cout is a multiple of 256
     if (a.N % 256 == 0) return (wr & 1) ? launch_halo<16, 256, true>(a, s) : launch_halo<16, 256, false>(a, s);
     // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile
