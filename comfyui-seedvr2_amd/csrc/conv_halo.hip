@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // W-through-registers kernel.  The W fragments never touch LDS: every wave loads them straight from the tiled global
-// layout into registers (one fully coalesced KiB per fragment), two taps ahead of their use.  Only the halo goes
+// layout into registers (one fully coalesced KiB per fragment), three taps ahead of their use.  Only the halo goes
 // through LDS, so the workgroup synchronises once per channel slice (nine taps, 288 MFMAs per wave) and the LDS-DMA
 // stream that the MFMA pipe was measured to wait for shrinks from 37-55 KiB to 7-13 KiB per super-step.
 //   * Wave tile = one 16 x 16 pixel block x 32 channels (16 x 2 MFMA 16x16x32): waves are laid out (PW/16) x (BN/32),
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     if (hrole) issue_halo(slice_base(0, 0), halo0);
     load_w(0, 0);
     load_w(1, 1);
+    load_w(2, 2);
 
     int tap_t = 0, cs = 0, hb = 0;
     for (int sl = 0; sl < nsl; ++sl) {
@@ -405,13 +406,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int tapi = kx * 3 + ky;                  // tap index inside the slice; ring slot = tapi % 3 = ky
-                load_w((ky + 2) % 3, u0 + tapi + 2);           // two taps ahead, into the slot freed by the last tap
-                __builtin_amdgcn_sched_barrier(0);             // or the scheduler sinks the loads next to their use
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < JN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ky][jn], af[i + ky], acc[i][jn], 0, 0, 0);
+                // the tap is done: refill its ring slot with the tap three ahead.  Issued AFTER the tap's MFMAs so that
+                // the (conservative, post-barrier) vmcnt wait in front of them never covers a load issued a moment
+                // ago; sched_barrier keeps the scheduler from sinking the load next to its use.
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(ky, u0 + tapi + 3);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         hb ^= 1;
