@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     const long long base = ((long long)f * P) * C + vec * 8;
     // frames >= f0 are also written to the consumer conv's carry buffer (its last kt - st input frames)
     bf16* const cdst = (carry && f >= f0) ? carry + ((long long)(f - f0) * P) * C + vec * 8 : nullptr;
-    for (long long p = p0 + prow; p < p1; p += ppb) {
-        const bf16x8 v = *(const bf16x8*)(x + base + p * C);
+    // four independent 16-byte loads in flight per thread (the pass is HBM-bound: latency x bandwidth needs ~10 MB in
+    // flight chip-wide); streaming data: non-temporal loads and stores keep it from displacing the conv weights in L2
+    auto one = [&](long long p, const bf16x8 v) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -113,9 +114,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
             if (SILU) t = t / (1.f + __expf(-t));
             o[e] = f2bf(t);
         }
-        *(bf16x8*)(y + base + p * C) = o;
+        __builtin_nontemporal_store(o, (bf16x8*)(y + base + p * C));
         if (cdst) *(bf16x8*)(cdst + p * C) = o;
+    };
+    long long p = p0 + prow;
+    for (; p + 3 * ppb < p1; p += 4 * ppb) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const bf16x8*)(x + base + (p + u * ppb) * C));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(p + u * ppb, v[u]);
     }
+    for (; p < p1; p += ppb) one(p, __builtin_nontemporal_load((const bf16x8*)(x + base + p * C)));
 }
 
 // ----------------------------------------------------------------------------- attention, head dim 512

@@ -99,6 +99,15 @@ def bench_norm(rows, dim):
     print(f"rmsnorm_mod {rows}x{dim}: {t*1e3:.3f} ms  {rows*dim*4/t/1e9:.0f} GB/s", flush=True)
 
 
+def bench_gn(F_, H, W, Cc):
+    x = rb(F_, H, W, Cc)
+    g, b = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    out = torch.empty_like(x)
+    t = timeit(lambda: hip.groupnorm_silu(x, g, b, 32, 1e-6, out=out))
+    nbytes = x.numel() * 2
+    print(f"groupnorm_silu (stats + apply) {tuple(x.shape)}: {t*1e3:.3f} ms  {3*nbytes/t/1e9:.0f} GB/s (2 reads + 1 write)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "conv", "attn", "norm"]
     if "gemm" in which:
@@ -113,6 +122,10 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "gn" in which:
+        bench_gn(4, 2160, 3840, 128)
+        bench_gn(4, 1080, 1920, 256)
+        bench_gn(4, 2160, 3840, 256)
     if "gemmsmall" in which:   # the memory-bound / narrow GEMMs of the VAE (run once per SVR2_GEMM_V value)
         print("SVR2_GEMM_V =", os.environ.get("SVR2_GEMM_V", "2"))
         bench_gemm(33177600, 128, 128)        # encoder conv_in after im2col, 4 frames at 4K
