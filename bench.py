@@ -312,7 +312,7 @@ def main():
                        "lr": [hin, win], "out": [th, tw], "padded": [ph, pw], "parallelism": f"frame-chunk x{world}",
                        "algorithmic_tflop_per_step": {"vae_encode": enc_f / 1e12, "dit_gemm": dit_f / 1e12,
                                                       "vae_decode": dec_f / 1e12}},
-            "roofline": {"bound": "mfma", "kernel": "conv_halo_kernel<16,256|32,128|64,16> (halo-resident causal conv3d, every 3x3 stride-1 conv of the VAE)",
+            "roofline": {"bound": "mfma", "kernel": "conv_halo_wr_kernel<16,256|32,128> + conv_halo_kernel<64,16> (halo-resident causal conv3d: every 3x3 stride-1 conv of the VAE)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic_cfg3.json)",

@@ -66,6 +66,7 @@ class QkvPrepDesc(C.Structure):
 
 _lib = None
 _zero_pages = {}
+_INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes")
 
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -74,6 +75,8 @@ EXPORTS = [
     "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
     "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles",
     "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
+    "svr2_wavelet_level", "svr2_wavelet_merge", "svr2_adain_ws_bytes", "svr2_adain", "svr2_rgb_to_lab",
+    "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
 ]
 
 
@@ -89,7 +92,7 @@ def lib() -> C.CDLL:
         _lib.svr2_last_error.restype = C.c_char_p
         for name in EXPORTS:
             if name != "svr2_last_error" and hasattr(_lib, name):
-                getattr(_lib, name).restype = C.c_int64 if name == "svr2_groupnorm_ws_floats" else C.c_int
+                getattr(_lib, name).restype = C.c_int64 if name in _INT64_RET else C.c_int
     return _lib
 
 
@@ -525,3 +528,82 @@ def crop_to_unit(x: torch.Tensor, h: int, w: int, to_unit: bool, out: Optional[t
                                    C.c_int32(h), C.c_int32(w), C.c_int32(1 if to_unit else 0), _stream()),
            "svr2_crop_to_unit")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- colour correction
+def _frames3(t: torch.Tensor, name: str):
+    _bf16c(t, name)
+    if t.dim() != 4 or t.shape[3] != 3 or not t.is_contiguous():
+        raise HipError(f"{name}: expected contiguous bf16 [F,H,W,3]")
+
+
+def wavelet_decomposition(x: torch.Tensor, levels: int = 5, want_high: bool = True):
+    """[F,H,W,3] bf16 -> (high, low) of the reference's dilated-Gaussian pyramid (high is None if not wanted)."""
+    _frames3(x, "wavelet.x")
+    Fr, H, W, _ = x.shape
+    high = torch.empty_like(x) if want_high else None
+    img = x
+    for i in range(levels):
+        radius = min(2 ** i, max(1, min(H, W) // 8))
+        low = torch.empty_like(x)
+        _check(lib().svr2_wavelet_level(_p(img), _p(low), _p(high), C.c_int32(Fr), C.c_int32(H), C.c_int32(W),
+                                        C.c_int32(radius), C.c_int32(1 if i == 0 else 0), _stream()), "svr2_wavelet_level")
+        img = low
+    return high, img
+
+
+def wavelet_reconstruction(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    if content.shape != style.shape:
+        raise HipError("wavelet_reconstruction: content and style must have the same shape")
+    high, _ = wavelet_decomposition(content, want_high=True)
+    _, low = wavelet_decomposition(style, want_high=False)
+    out = torch.empty_like(content)
+    _check(lib().svr2_wavelet_merge(_p(high), _p(low), _p(out), C.c_int64(out.numel()), _stream()), "svr2_wavelet_merge")
+    return out
+
+
+def adain(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    _frames3(content, "adain.content"); _frames3(style, "adain.style")
+    if content.shape != style.shape:
+        raise HipError("adain: content and style must have the same shape")
+    Fr, H, W, _ = content.shape
+    ws = torch.empty(int(lib().svr2_adain_ws_bytes(C.c_int32(Fr), C.c_int64(H * W))), dtype=torch.uint8, device=content.device)
+    out = torch.empty_like(content)
+    _check(lib().svr2_adain(_p(content), _p(style), _p(out), C.c_int32(Fr), C.c_int64(H * W), _p(ws), _stream()), "svr2_adain")
+    return out
+
+
+def lab_color_transfer(content: torch.Tensor, style: torch.Tensor, luminance_weight: float = 0.8) -> torch.Tensor:
+    """Wavelet reconstruction, then CIELAB histogram matching of a*, b* (and partly L*) over the whole batch."""
+    base = wavelet_reconstruction(content, style)
+    n = base.numel() // 3
+    dev = base.device
+    cl = torch.empty(3, n, dtype=torch.float32, device=dev)
+    sl = torch.empty(3, n, dtype=torch.float32, device=dev)
+    _check(lib().svr2_rgb_to_lab(_p(base), _p(cl), C.c_int64(n), _stream()), "svr2_rgb_to_lab")
+    _check(lib().svr2_rgb_to_lab(_p(style), _p(sl), C.c_int64(n), _stream()), "svr2_rgb_to_lab")
+    nws = int(lib().svr2_hist_match_ws_bytes(C.c_int64(n)))
+    if nws <= 0:
+        raise HipError("lab_color_transfer: batch too large for one histogram match")
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    matched = torch.empty(3, n, dtype=torch.float32, device=dev)
+    chans = (0, 1, 2) if luminance_weight < 1.0 else (1, 2)
+    for c in chans:
+        _check(lib().svr2_hist_match(_p(cl[c]), _p(sl[c]), _p(matched[c]), C.c_int64(n), _p(ws), C.c_int64(nws), _stream()),
+               "svr2_hist_match")
+    out = torch.empty_like(base)
+    _check(lib().svr2_lab_to_rgb(_p(cl[0]), _p(matched[0]) if luminance_weight < 1.0 else None, _p(matched[1]),
+                                 _p(matched[2]), C.c_float(luminance_weight), _p(out), C.c_int64(n), _stream()),
+           "svr2_lab_to_rgb")
+    return out
+
+
+COLOR_METHODS = {"lab": lab_color_transfer, "wavelet": wavelet_reconstruction, "adain": adain}
+
+
+def color_correct(sample: torch.Tensor, input_video: torch.Tensor, method: str) -> torch.Tensor:
+    """Phase-4 colour correction of a decoded batch [T,H,W,3] in [-1,1] against the transformed input of the same frames
+    [ref: src/core/generation_phases.py:1290-1304].  'hsv' and 'wavelet_adaptive' are not implemented."""
+    if method not in COLOR_METHODS:
+        raise HipError(f"color_correction '{method}' is not implemented (available: none, {', '.join(COLOR_METHODS)})")
+    return COLOR_METHODS[method](sample, input_video)

@@ -10,6 +10,7 @@ from typing import Any, Dict
 import torch
 
 from . import dit as _dit
+from . import hip
 from . import pipeline as _pipeline
 from . import vae as _vae
 from . import weights as _weights
@@ -95,8 +96,9 @@ class SeedVR2VideoUpscaler(_Base):
             raise ValueError("image must be [N,H,W,3|4]")
         if image.shape[-1] == 4:
             raise NotImplementedError("RGBA alpha upscaling is out of scope (SURVEY 8f next-4)")
-        if color_correction != "none":
-            raise NotImplementedError("colour correction runs after the hot path (SURVEY 8f next-2); use 'none'")
+        if color_correction not in ("none",) + tuple(hip.COLOR_METHODS):
+            raise NotImplementedError(f"color_correction '{color_correction}' is not implemented "
+                                      f"(available: none, {', '.join(hip.COLOR_METHODS)})")
         if input_noise_scale or latent_noise_scale:
             raise NotImplementedError("noise injection scales other than 0 are not implemented")
         if batch_size % 4 != 1:
@@ -106,7 +108,8 @@ class SeedVR2VideoUpscaler(_Base):
         if prepend_frames > 0:  # reversed head frames, removed from the output [ref: generation_utils.py:593-652]
             n = min(prepend_frames, max(image.shape[0] - 1, 0))
             frames = torch.cat((image[1:n + 1].flip(0), image), dim=0) if n > 0 else image
-        out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size)
+        out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size,
+                            color_correction=color_correction)
         if prepend_frames > 0 and frames.shape[0] != image.shape[0]:
             out = out[frames.shape[0] - image.shape[0]:]
         return (out.float().cpu(),)

@@ -181,8 +181,13 @@ class SeedVR2Pipeline:
     @torch.no_grad()
     def generate(self, frames: torch.Tensor, resolution: int, batch_size: int = 5, temporal_overlap: int = 0,
                  seed: int = 42, max_resolution: int = 0, uniform_batch_size: bool = False,
-                 progress=None) -> torch.Tensor:
-        """frames [N,Hin,Win,3] float in [0,1] (any device) -> bf16 [N,true_h,true_w,3] in [0,1] on the device."""
+                 progress=None, color_correction: str = "none") -> torch.Tensor:
+        """frames [N,Hin,Win,3] float in [0,1] (any device) -> bf16 [N,true_h,true_w,3] in [0,1] on the device.
+        color_correction: 'none', 'lab', 'wavelet' or 'adain' (phase 4, against the transformed input of each batch
+        [ref: src/core/generation_phases.py:1237-1304])."""
+        if color_correction != "none" and color_correction not in hip.COLOR_METHODS:
+            raise hip.HipError(f"color_correction '{color_correction}' is not implemented "
+                               f"(available: none, {', '.join(hip.COLOR_METHODS)})")
         N, hin, win, _ = frames.shape
         rh, rw, th, tw, ph, pw = target_dims(hin, win, resolution, max_resolution)
         batches, overlap = plan_batches(N, batch_size, temporal_overlap, uniform_batch_size)
@@ -191,19 +196,33 @@ class SeedVR2Pipeline:
         final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16, device=self.device)
         w_prev = blend_weights(overlap).to(self.device) if overlap else None
         write = 0
+        written = []   # (first frame, end frame, batch, frames of the batch that went into the previous slice)
         for bi, b in enumerate(batches):
             idx = torch.tensor(b.index, device=self.device)
             dec = self.upscale_batch(src.index_select(0, idx).contiguous(), resolution, seed, max_resolution)
             sample = hip.crop_to_unit(dec[: b.ori_len].contiguous(), th, tw, to_unit=False)  # trim temporal+spatial pad
             del dec
+            skipped = 0
             if bi > 0 and overlap and overlap < sample.shape[0] and write >= overlap:
                 tail = final[write - overlap:write]
                 hip.blend_overlap(tail.clone(), sample[:overlap].contiguous(), w_prev, tail)
                 sample = sample[overlap:]
+                skipped = overlap
             final[write:write + sample.shape[0]] = sample
+            written.append((write, write + sample.shape[0], bi, skipped))
             write += sample.shape[0]
             if progress:
                 progress(bi + 1, len(batches))
         final = final[:write]
-        # phase 4 with color_correction='none': clamp(-1,1)*0.5+0.5  [ref: generation_phases.py:1337]
+        if color_correction != "none":
+            # phase 4: every batch's slice of the blended video is matched to the transformed input of the same frames
+            # (re-created on demand like the reference's _reconstruct_and_transform_batch, generation_phases.py:1237-1262)
+            for ws, we, bi, skipped in written:
+                b = batches[bi]
+                idx = torch.tensor(b.index, device=self.device)
+                x = self.transform(src.index_select(0, idx).contiguous(), resolution, max_resolution)
+                x = hip.crop_to_unit(x[: b.ori_len].contiguous(), th, tw, to_unit=False)
+                x = x[skipped:skipped + (we - ws)].contiguous()
+                final[ws:we] = hip.color_correct(final[ws:we].contiguous(), x, color_correction)
+        # phase 4 tail: clamp(-1,1)*0.5+0.5  [ref: generation_phases.py:1337]
         return hip.crop_to_unit(final, th, tw, to_unit=True)

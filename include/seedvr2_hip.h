@@ -244,6 +244,34 @@ int svr2_blend_overlap(const void* prev_tail, const void* cur_head, void* out, c
 int svr2_crop_to_unit(const void* in, void* out, int32_t T, int32_t Hp, int32_t Wp, int32_t H, int32_t W,
                       int32_t to_unit, void* stream);
 
+/* ------------------------------------------------------------------ phase-4 colour correction
+ * Channels-last bf16 frames [F, H, W, 3] in [-1, 1]; content = decoded sample, style = transformed input of the same
+ * frames [ref: src/core/generation_phases.py:1290-1304, src/utils/color_fix.py].  The reference runs these in the
+ * compute dtype (bf16): the kernels round to bf16 after the same ops.
+ *
+ * svr2_wavelet_level: one level of the dilated-Gaussian pyramid [ref: color_fix.py:122-184]:
+ *   low = conv3x3(img; 1/16 [1 2 1; 2 4 2; 1 2 1], dilation = radius, replicate padding);
+ *   high = (first ? 0 : high) + img - low   (high may be NULL).  radius = min(2^level, max(1, min(H,W)/8)).
+ * svr2_wavelet_merge: out = clamp(high + low, -1, 1)                         [ref: color_fix.py:241-246]
+ * svr2_adain: per (frame, channel) (x - mean_c) / std_c * std_s + mean_s      [ref: color_fix.py:72-119]
+ * svr2_rgb_to_lab: planar fp32 lab[3][n] of clamp((x+1)/2, 0, 1), D65         [ref: color_fix.py:322-329,368-411]
+ * svr2_hist_match: out[rank-i element of source] = i-th smallest of reference [ref: color_fix.py:473-513]
+ *   (device radix sort; equal source values receive consecutive reference quantiles in index order - the
+ *    reference leaves that order unspecified)
+ * svr2_lab_to_rgb: L = Lc*lw + Lm*(1-lw) (Lm may be NULL), lab -> rgb -> bf16 [-1,1]   [ref: color_fix.py:335-361,414-470]
+ */
+int svr2_wavelet_level(const void* img, void* low, void* high, int32_t F, int32_t H, int32_t W, int32_t radius,
+                       int32_t first, void* stream);
+int svr2_wavelet_merge(const void* high, const void* low, void* out, int64_t n, void* stream);
+int64_t svr2_adain_ws_bytes(int32_t F, int64_t P);
+int svr2_adain(const void* content, const void* style, void* out, int32_t F, int64_t P, void* workspace, void* stream);
+int svr2_rgb_to_lab(const void* x, float* lab, int64_t n, void* stream);
+int64_t svr2_hist_match_ws_bytes(int64_t n);
+int svr2_hist_match(const float* source, const float* reference, float* out, int64_t n, void* workspace,
+                    int64_t ws_bytes, void* stream);
+int svr2_lab_to_rgb(const float* L_content, const float* L_matched, const float* a, const float* b,
+                    float luminance_weight, void* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ def _install_name_stubs():
     mod("diffusers.models")
     mod("diffusers.models.normalization", RMSNorm=type("RMSNorm", (torch.nn.Module,), {}))
     mod("rotary_embedding_torch", RotaryEmbedding=_Name, apply_rotary_emb=None)
+    # color_fix.py imports two converter NAMES from torchvision (used only by its PIL entry points, never here)
+    mod("torchvision")
+    mod("torchvision.transforms", ToTensor=_Name, ToPILImage=_Name)
 
 
 def check(name, a, b, tol=0.0):
@@ -332,6 +335,36 @@ def main():
         check("G10 remove_head", torch.cat((xh[0][:, :1], xh[0][:, 2:]), dim=1), cil.remove_head(xh)[0])
     vt.update({"G10.gn.x": xg[0], "G10.gn.w": gn.weight.detach(), "G10.gn.b": gn.bias.detach(), "G10.gn.y": ref[0]})
     save_file({k: v.contiguous() for k, v in vt.items()}, os.path.join(GOLD, "vae_pins.safetensors"))
+
+    # ------------------------------------------------------------------ G12 phase-4 colour correction (next-2)
+    import importlib
+    cf = importlib.import_module("src.utils.color_fix")
+    from seedvr2_ref import color as ocol
+
+    class _Dbg:
+        def log(self, *a, **k):
+            pass
+
+    ct = {}
+    g = torch.Generator().manual_seed(77)
+    base = torch.rand(2, 3, 6, 8, generator=g)
+    style32 = torch.nn.functional.interpolate(base, size=(40, 56), mode="bicubic").clamp(0, 1) * 2 - 1
+    content32 = (style32 * 0.8 + 0.1 + 0.05 * torch.randn(2, 3, 40, 56, generator=g)).clamp(-1, 1)
+    for tag, dt, tol in (("f32", torch.float32, 1e-6), ("bf16", torch.bfloat16, 0.0)):
+        c, s_ = content32.to(dt), style32.to(dt)
+        r_ad = cf.adaptive_instance_normalization(c.clone(), s_.clone())
+        check(f"G12 adain {tag}", ocol.adaptive_instance_normalization(c.clone(), s_.clone()).float(), r_ad.float(), tol)
+        r_wv = cf.wavelet_reconstruction(c.clone(), s_.clone(), _Dbg())
+        check(f"G12 wavelet_reconstruction {tag}", ocol.wavelet_reconstruction(c.clone(), s_.clone()).float(), r_wv.float(), tol)
+        r_lab = cf.lab_color_transfer(c.clone(), s_.clone(), _Dbg(), luminance_weight=0.8)
+        check(f"G12 lab_color_transfer {tag}", ocol.lab_color_transfer(c.clone(), s_.clone()).float(), r_lab.float(),
+              2e-6 if dt == torch.float32 else 0.0)
+        ct.update({f"G12.{tag}.content": c, f"G12.{tag}.style": s_, f"G12.{tag}.adain": r_ad, f"G12.{tag}.wavelet": r_wv,
+                   f"G12.{tag}.lab": r_lab})
+    lab = cf._rgb_to_lab_batch((style32 + 1) / 2, torch.device("cpu"), torch.tensor(ocol._RGB2XYZ), ocol.EPS, ocol.KAPPA)
+    check("G12 rgb->lab", ocol.rgb_to_lab((style32 + 1) / 2), lab, 1e-5)
+    ct["G12.lab_of_style"] = lab
+    save_file({k: v.contiguous() for k, v in ct.items()}, os.path.join(GOLD, "color_pins.safetensors"))
 
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
     with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:

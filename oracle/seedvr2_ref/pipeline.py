@@ -96,7 +96,7 @@ def make_noise(shape, seed):
 
 def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, resolution: int, batch_size: int = 5,
              temporal_overlap: int = 0, seed: int = 42, dtype=torch.float32, uniform_batch_size: bool = False,
-             taps: dict | None = None) -> torch.Tensor:
+             taps: dict | None = None, color_correction: str = "none") -> torch.Tensor:
     """frames [N,H,W,3] float in [0,1] -> [N,true_h,true_w,3] in [0,1] (dtype bf16 storage between phases,
     model arithmetic in `dtype`)."""
     N, H, W, _ = frames.shape
@@ -105,6 +105,7 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
     src = frames.to(torch.bfloat16)
     final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16)
     write = 0
+    written = []
     for bi, (s, e) in enumerate(ranges):
         vid = src[s:e]
         ori = e - s
@@ -120,10 +121,19 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
         if taps is not None and bi == 0:
             taps.update(x=x, latent=latent, x0=x0, dec=dec)
         sample = dec.permute(1, 0, 2, 3)[:ori, :, :th, :tw].permute(0, 2, 3, 1)     # [T,H,W,3]
+        skipped = 0
         if bi > 0 and overlap and overlap < sample.shape[0] and write >= overlap:
             final[write - overlap:write] = blend_overlapping_frames(final[write - overlap:write], sample[:overlap], overlap)
             sample = sample[overlap:]
+            skipped = overlap
         final[write:write + sample.shape[0]] = sample
+        # transformed input of the frames this batch wrote (generation_phases.py:1237-1262)
+        xin = x.permute(1, 0, 2, 3)[:ori, :, :th, :tw].permute(0, 2, 3, 1)[skipped:skipped + sample.shape[0]]
+        written.append((write, write + sample.shape[0], xin.contiguous()))
         write += sample.shape[0]
     final = final[:write]
+    if color_correction != "none":                                    # generation_phases.py:1290-1304
+        from . import color as _color
+        for ws, we, xin in written:
+            final[ws:we] = _color.color_correct(final[ws:we].contiguous(), xin, color_correction)
     return final.clamp(-1, 1).mul(0.5).add(0.5)                       # generation_phases.py:1337

@@ -118,3 +118,26 @@ def test_oracle_pipeline_runs_tiny():
     assert out.shape == (3, 32, 48, 3) and out.min() >= 0 and out.max() <= 1
     out2 = opipe.generate(frames, vp, vcfg, dp, dcfg, txt, resolution=32, batch_size=5, seed=7)
     assert torch.equal(out, out2)
+
+
+def test_color_oracle_matches_reference_golden():
+    """Phase-4 colour correction: the oracle's adain / wavelet / lab against outputs of the
+    reference's own color_fix.py (tests/golden/color_pins.safetensors, written by oracle/pin_against_reference.py)."""
+    from seedvr2_ref import color as ocol
+    t = load_file(os.path.join(ROOT, "tests", "golden", "color_pins.safetensors"))
+    for tag, tol in (("f32", 2e-5), ("bf16", 1.6e-2)):      # bf16: one ulp at |v| ~ 1 (conv accumulation order of the host)
+        c, s_ = t[f"G12.{tag}.content"], t[f"G12.{tag}.style"]
+        for name, fn in (("adain", ocol.adaptive_instance_normalization), ("wavelet", ocol.wavelet_reconstruction),
+                         ("lab", ocol.lab_color_transfer)):
+            got = fn(c.clone(), s_.clone()).float()
+            ref = t[f"G12.{tag}.{name}"].float()
+            assert got.shape == ref.shape
+            assert (got - ref).abs().max().item() <= tol, (tag, name)
+    lab = ocol.rgb_to_lab((t["G12.f32.style"] + 1) / 2)
+    assert (lab - t["G12.lab_of_style"]).abs().max().item() <= 1e-4
+    # histogram matching moves the reference's value multiset onto the source ranks
+    g = torch.Generator().manual_seed(3)
+    src, ref = torch.randn(5, 7, 9, generator=g), torch.randn(5, 7, 9, generator=g) * 2 + 1
+    out = ocol.histogram_match(src, ref)
+    assert torch.equal(out.flatten().sort().values, ref.flatten().sort().values)
+    assert torch.equal(out.flatten().argsort(), src.flatten().argsort())

@@ -131,8 +131,56 @@ def test_vae_decode_vs_oracle_and_chunking(pkg, gpu):
     assert _rel(whole, got) < 5e-3 and _rel(ref_sched, got) < 5e-3
 
 
-def test_pipeline_end_to_end_psnr(pkg, gpu):
-    """LR clip -> upscaled clip, two overlapping batches: HIP path vs fp32 oracle on decoded RGB in [0,1]."""
+def _color_pair(T=3, H=40, W=56, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(T, 3, 6, 8, generator=g)
+    style = F.interpolate(base, size=(H, W), mode="bicubic").clamp(0, 1) * 2 - 1
+    content = (style * 0.8 + 0.1 + 0.05 * torch.randn(T, 3, H, W, generator=g)).clamp(-1, 1)
+    to = lambda x: x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    return to(content), to(style)
+
+
+@pytest.mark.parametrize("method", ["wavelet", "adain", "lab"])
+def test_color_correction_vs_oracle(pkg, gpu, method):
+    """Phase-4 colour correction kernels (color.hip) against the oracle (pinned on the reference's color_fix.py) on
+    bf16 frames.  Tolerance: the reference rounds to bf16 after every op, the kernels round at the same places but
+    accumulate the 3x3 stencil / moments in a different order: <= 2 bf16 ulp at |v| ~ 1 (1.6e-2) per pixel, and a mean
+    error far below one ulp; LAB adds pow() differences and the unspecified order of tied ranks (see oracle)."""
+    from seedvr2_ref import color as ocol
+    c, s_ = _color_pair()
+    ref = ocol.color_correct(c.clone(), s_.clone(), method).float()
+    got = pkg.hip.color_correct(c.to(gpu), s_.to(gpu), method).float().cpu()
+    d = (got - ref).abs()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert d.max().item() <= (4e-2 if method == "lab" else 1.6e-2), d.max().item()
+    assert d.mean().item() <= (2e-3 if method == "lab" else 5e-4), d.mean().item()
+
+
+def test_hist_match_is_a_rank_transfer(pkg, gpu):
+    """svr2_hist_match (device radix sorts): the output holds exactly the reference's values, in the source's rank
+    order - bit for bit when the source has no ties."""
+    import ctypes as C
+    hip = pkg.hip
+    n = 200_003
+    g = torch.Generator().manual_seed(11)
+    src = (torch.randperm(n, generator=g).float() - n / 2) / 1024     # distinct values, negative and positive
+    ref = torch.randn(n, generator=g) * 3 - 1
+    assert src.unique().numel() == n
+    ws_n = int(hip.lib().svr2_hist_match_ws_bytes(C.c_int64(n)))
+    ws = torch.empty(ws_n, dtype=torch.uint8, device=gpu)
+    out = torch.empty(n, dtype=torch.float32, device=gpu)
+    sd, rd = src.to(gpu), ref.to(gpu)
+    hip._check(hip.lib().svr2_hist_match(hip._p(sd), hip._p(rd), hip._p(out), C.c_int64(n), hip._p(ws), C.c_int64(ws_n),
+                                         hip._stream()), "svr2_hist_match")
+    want = torch.empty(n)
+    want[src.argsort()] = ref.sort().values
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("cc", ["none", "lab", "wavelet"])
+def test_pipeline_end_to_end_psnr(pkg, gpu, cc):
+    """LR clip -> upscaled clip, two overlapping batches (+ phase-4 colour correction): HIP path vs fp32 oracle on
+    decoded RGB in [0,1]."""
     from seedvr2_ref import dit as odit, pipeline as opipe
     ovae, ocfg, vp, vae = _vae_pair(pkg, gpu, seed=1)
     kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=2, mm_layers=1, txt_in_dim=64, mlp_multiple_of=64)
@@ -144,12 +192,12 @@ def test_pipeline_end_to_end_psnr(pkg, gpu):
     lr = F.interpolate(lr.permute(0, 3, 1, 2), size=(16, 24), mode="bicubic").permute(0, 2, 3, 1).clamp(0, 1)
     lr = (lr * 255).round() / 255  # uint8-quantised like the CLI input
     pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
-    got = pipe.generate(lr, resolution=32, batch_size=5, temporal_overlap=2, seed=42).float().cpu()
-    ref32 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.float32).float()
-    ref16 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.bfloat16).float()
+    got = pipe.generate(lr, resolution=32, batch_size=5, temporal_overlap=2, seed=42, color_correction=cc).float().cpu()
+    ref32 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.float32, color_correction=cc).float()
+    ref16 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.bfloat16, color_correction=cc).float()
     assert got.shape == ref32.shape == (7, 32, 48, 3)
     p_hip, p_b16 = psnr(got, ref32), psnr(ref16, ref32)
-    print(f"end-to-end PSNR vs fp32 oracle: hip={p_hip:.2f} dB, bf16 oracle={p_b16:.2f} dB, "
+    print(f"end-to-end PSNR vs fp32 oracle (color_correction={cc}): hip={p_hip:.2f} dB, bf16 oracle={p_b16:.2f} dB, "
           f"max|d|={float((got - ref32).abs().max()):.4f}")
     assert p_hip >= p_b16 - 3.0 and p_hip > 30.0
 

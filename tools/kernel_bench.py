@@ -108,6 +108,15 @@ def bench_gn(F_, H, W, Cc):
     print(f"groupnorm_silu (stats + apply) {tuple(x.shape)}: {t*1e3:.3f} ms  {3*nbytes/t/1e9:.0f} GB/s (2 reads + 1 write)", flush=True)
 
 
+def bench_color(T, H, W):
+    c = (torch.rand(T, H, W, 3, device=dev) * 2 - 1).to(torch.bfloat16)
+    s_ = (torch.rand(T, H, W, 3, device=dev) * 2 - 1).to(torch.bfloat16)
+    nbytes = c.numel() * 2
+    for m in ("wavelet", "adain", "lab"):
+        t = timeit(lambda: hip.color_correct(c, s_, m), iters=3, warm=1)
+        print(f"color_correct[{m}] {T}x{H}x{W}: {t*1e3:.1f} ms  ({nbytes/1e9:.2f} GB per tensor, {T/t:.1f} frames/s)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "conv", "attn", "norm"]
     if "gemm" in which:
@@ -122,6 +131,8 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "color" in which:
+        bench_color(17, 2160, 3840)
     if "gn" in which:
         bench_gn(4, 2160, 3840, 128)
         bench_gn(4, 1080, 1920, 256)
