@@ -296,7 +296,7 @@ def main():
         if args.workload == "cfg3" and os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
-                    traffic = json.load(fh)["kernels"]["conv3d halo-resident (conv_halo_kernel)"]["hbm_bytes_per_launch"]
+                    traffic = json.load(fh)["kernels"]["conv3d halo-resident (conv_halo*_kernel)"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         result = {
