@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16* __restrict
 }
 
 // ----------------------------------------------------------------------------- qkv preparation
-// Work item = (position s, tensor o in {q,k,v}, group of 4 heads): 64 lanes x 8 dims = 4 heads x 128.
+// Work item = (position s, group of 4 heads), its q, k and v rows: 64 lanes x 8 dims = 4 heads x 128 per tensor.
 // A head's 128 dims sit on 16 consecutive lanes -> 16-lane segmented reduction for the RMS.
 // RoPE pairs (2i, 2i+1) are inside a lane's 8 dims; pair index p = dim/2 in [0,63):
 // axis = p / nfreq, freq = p % nfreq, pairs >= 3*nfreq pass through.
@@ -76,42 +76,30 @@ struct PrepArgs {
 __global__ __launch_bounds__(256) void qkv_prep_kernel(const PrepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hq = (a.H + 3) >> 2;          // head quads per tensor
-    const long long items = a.S * 3 * hq;
+    const long long items = a.S * hq;       // one item = (position, head quad): its q, k and v rows (3 KiB in flight per wave)
     const int sub = lane >> 4, l16 = lane & 15;
     const long long row_elems = 3ll * a.H * 128;
     for (long long it = (long long)blockIdx.x * 4 + wave; it < items; it += (long long)gridDim.x * 4) {
-        const long long s = it / (3 * hq);
-        const int rem = (int)(it - s * (3 * hq));
-        const int o = rem / hq, quad = rem - o * hq;
+        const long long s = it / hq;
+        const int quad = (int)(it - s * hq);
         const int head = quad * 4 + sub;
         const int src = a.src_row[s];
         const bool is_txt = src < 0;
         const bf16* base = is_txt ? a.qkv_txt + (long long)(-1 - src) * row_elems : a.qkv_vid + (long long)src * row_elems;
         const bool hv = head < a.H;
-        bf16x8 val;
-        if (hv) val = *(const bf16x8*)(base + ((long long)o * a.H + head) * 128 + l16 * 8);
-        else
+        bf16x8 val[3];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = f2bf(0.f);
-        bf16* dst = (o == 0 ? a.q : (o == 1 ? a.k : a.v)) + (s * a.H + head) * 128 + l16 * 8;
-        if (o == 2) {  // v: plain gather
-            if (hv) *(bf16x8*)dst = val;
-            continue;
+        for (int o = 0; o < 3; ++o) {
+            if (hv) val[o] = *(const bf16x8*)(base + ((long long)o * a.H + head) * 128 + l16 * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[o][e] = f2bf(0.f);
         }
-        float f[8];
-        float ss = 0.f;
+        const bool rope = a.rope_mode == 1 || (a.rope_mode == 2 && !is_txt);
+        float rc[4], rs[4];                 // this lane's four rotation pairs (shared by q and k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            f[e] = bf2f(val[e]);
-            ss += f[e] * f[e];
-        }
-#pragma unroll
-        for (int m = 8; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 64);  // stays inside the 16-lane segment
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.f) + a.eps);
-        const float* nw = (o == 0) ? (is_txt ? a.qn_txt : a.qn_vid) : (is_txt ? a.kn_txt : a.kn_vid);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * nw[l16 * 8 + e];
-        if (a.rope_mode == 1 || (a.rope_mode == 2 && !is_txt)) {
+        for (int pr = 0; pr < 4; ++pr) { rc[pr] = 1.f; rs[pr] = 0.f; }
+        if (rope) {
             const int pt = a.pos[s * 3 + 0], ph = a.pos[s * 3 + 1], pw = a.pos[s * 3 + 2];
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
@@ -119,26 +107,48 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const PrepArgs a) {
                 const int axis = p / a.nfreq;
                 if (axis < 3) {
                     const int fi = p - axis * a.nfreq;
-                    float c, sn;
                     if (a.rope_mode == 1) {
                         const int pv = axis == 0 ? pt : (axis == 1 ? ph : pw);
-                        c = a.rope_cos[pv * a.nfreq + fi];
-                        sn = a.rope_sin[pv * a.nfreq + fi];
+                        rc[pr] = a.rope_cos[pv * a.nfreq + fi];
+                        rs[pr] = a.rope_sin[pv * a.nfreq + fi];
                     } else {  // per-position tables [S, 3*nfreq]
-                        c = a.rope_cos[s * (3 * a.nfreq) + p];
-                        sn = a.rope_sin[s * (3 * a.nfreq) + p];
+                        rc[pr] = a.rope_cos[s * (3 * a.nfreq) + p];
+                        rs[pr] = a.rope_sin[s * (3 * a.nfreq) + p];
                     }
-                    const float x1 = f[2 * pr], x2 = f[2 * pr + 1];
-                    f[2 * pr] = x1 * c - x2 * sn;
-                    f[2 * pr + 1] = x2 * c + x1 * sn;
                 }
             }
         }
-        if (hv) {
-            bf16x8 o8;
+        const long long doff = (s * a.H + head) * 128 + l16 * 8;
+        if (hv) *(bf16x8*)(a.v + doff) = val[2];   // v: plain gather
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = f2bf(f[e]);
-            *(bf16x8*)dst = o8;
+        for (int o = 0; o < 2; ++o) {
+            float f[8];
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] = bf2f(val[o][e]);
+                ss += f[e] * f[e];
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 64);  // stays inside the 16-lane segment
+            const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.f) + a.eps);
+            const float* nw = (o == 0) ? (is_txt ? a.qn_txt : a.qn_vid) : (is_txt ? a.kn_txt : a.kn_vid);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * nw[l16 * 8 + e];
+            if (rope) {
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const float x1 = f[2 * pr], x2 = f[2 * pr + 1];
+                    f[2 * pr] = x1 * rc[pr] - x2 * rs[pr];
+                    f[2 * pr + 1] = x2 * rc[pr] + x1 * rs[pr];
+                }
+            }
+            if (hv) {
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = f2bf(f[e]);
+                *(bf16x8*)((o == 0 ? a.q : a.k) + doff) = o8;
+            }
         }
     }
 }
@@ -314,7 +324,7 @@ extern "C" int svr2_qkv_prep(const svr2_qkv_prep_desc* d, void* stream) {
     a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin;
     a.q = (bf16*)d->q; a.k = (bf16*)d->k; a.v = (bf16*)d->v;
     a.S = d->S; a.H = d->H; a.nfreq = d->nfreq; a.max_pos = d->max_pos; a.rope_mode = d->rope_mode; a.eps = d->eps;
-    const long long items = a.S * 3 * ((a.H + 3) / 4);
+    const long long items = a.S * ((a.H + 3) / 4);
     hipLaunchKernelGGL(qkv_prep_kernel, dim3(grid_for(items, 4)), dim3(256), 0, (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
