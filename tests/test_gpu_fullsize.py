@@ -33,24 +33,36 @@ def test_gemm_onehot_rows_fullsize(pkg, gpu):
     assert torch.isfinite(out.float()).all()
 
 
-def test_conv3d_delta_input_fullsize(pkg, gpu):
-    """One-hot input pixel in a 4-frame 4K chunk with a carried head: the output is the (flipped) filter
-    placed around that pixel plus bias, everywhere else bias only - bit exact.  Pixels sit at the image
-    border, at a patch-tile corner and in the carry, so zero padding, 2-D patch tiles and the causal head
-    are all hit at full resolution."""
+@pytest.mark.parametrize("H,W,Cin,Cout,tiled", [
+    (2160, 3840, 128, 128, False),     # tap-staged kernels (row weight layout)
+    (2160, 3840, 128, 128, True),      # conv_halo_wr_kernel<32,128>: 512-pixel x 128-channel blocks
+    (1080, 1920, 256, 256, True),      # conv_halo_wr_kernel<16,256>; 1080 = 67.5 patches: ragged last patch row
+    (2160, 3840, 128, 3, True),        # conv_halo_kernel<64,16>: conv_out
+])
+def test_conv3d_delta_input_fullsize(pkg, gpu, H, W, Cin, Cout, tiled):
+    """One-hot input pixels in a 4-frame chunk with a carried head: the output is the (flipped) filter placed around
+    each pixel plus bias, everywhere else bias only - bit exact.  Pixels sit at the image border, at patch corners and
+    in the carry, so zero padding, the 2-D patch tiles / halo loads and the causal head are all hit at full size; the
+    GroupNorm partial sums of the halo kernels must fold to the sums of the stored output."""
     hip = pkg.hip
-    T, H, W, C = 4, 2160, 3840, 128
+    T = 4
     g = torch.Generator(device=gpu).manual_seed(1)
-    wt = torch.randn(C, 3, 3, 3, C, generator=g, device=gpu).to(torch.bfloat16)      # [Cout,kt,kh,kw,Cin]
-    bias = torch.randn(C, generator=g, device=gpu)
-    x = torch.zeros(T, H, W, C, dtype=torch.bfloat16, device=gpu)
-    carry = torch.zeros(2, H, W, C, dtype=torch.bfloat16, device=gpu)
-    hot = [("x", 1, 0, 0, 5), ("x", 3, 2159, 3839, 77), ("x", 2, 1079, 1919, 0), ("x", 0, 8, 16, 127),
-           ("c", 1, 500, 700, 31)]
+    wt = torch.randn(Cout, 3, 3, 3, Cin, generator=g, device=gpu).to(torch.bfloat16)      # [Cout,kt,kh,kw,Cin]
+    bias = torch.randn(Cout, generator=g, device=gpu)
+    x = torch.zeros(T, H, W, Cin, dtype=torch.bfloat16, device=gpu)
+    carry = torch.zeros(2, H, W, Cin, dtype=torch.bfloat16, device=gpu)
+    hot = [("x", 1, 0, 0, 5), ("x", 3, H - 1, W - 1, Cin - 51), ("x", 2, H // 2 - 1, W // 2 - 1, 0), ("x", 0, 8, 16, Cin - 1),
+           ("x", 2, 15, 31, 40), ("x", 3, 48, 96, 41), ("c", 1, 500, 700, 31)]
     for src, t, y, xx, c in hot:
         (x if src == "x" else carry)[t, y, xx, c] = 1.0
-    out = hip.conv3d(x, hip.pad_weight(hip.conv_weight(wt.permute(0, 4, 1, 2, 3))), C, (3, 3, 3), npad=2, carry=carry,
-                     bias=bias)
+    w5 = wt.permute(0, 4, 1, 2, 3)
+    stats = tiled and Cout % 8 == 0
+    if tiled:
+        res = hip.conv3d(x, hip.conv_weight_tiled(w5), Cout, (3, 3, 3), npad=2, carry=carry, bias=bias,
+                         w_layout=hip.WL_TILED_128x32, gn_stats=stats)
+        out, part = res if stats else (res, None)
+    else:
+        out = hip.conv3d(x, hip.pad_weight(hip.conv_weight(w5)), Cout, (3, 3, 3), npad=2, carry=carry, bias=bias)
     b16 = bias.to(torch.bfloat16)
     # padded frame index p: carry frames 0,1 ; chunk frame t -> p = t + 2 ; output t' reads p in [t', t'+2]
     touched = torch.zeros(T, H, W, dtype=torch.bool, device=gpu)
@@ -67,6 +79,11 @@ def test_conv3d_delta_input_fullsize(pkg, gpu):
                         touched[tp, oy, ox] = True
     rest = out[~touched]
     assert torch.equal(rest, b16.expand_as(rest))
+    if stats:
+        of = out.float()
+        sums = part.buf.double().sum(dim=1)
+        want = torch.stack((of.sum(dim=(1, 2)), (of * of).sum(dim=(1, 2))), dim=1).double()
+        assert ((sums - want).abs() <= 1e-4 * want.abs() + 1e-2).all()
 
 
 def test_window_attention_softmax_rows_fullsize(pkg, gpu):
