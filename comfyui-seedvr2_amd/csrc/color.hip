@@ -15,8 +15,14 @@ __device__ __forceinline__ float rbf(float v) { return bf2f(f2bf(v)); }   // one
 // ----------------------------------------------------------------------------- wavelet level
 // low = bf16(sum_{3x3} k[dy][dx] * img[clamp(y + (dy-1)*r), clamp(x + (dx-1)*r)])   (replicate padding, dilation r)
 // high = bf16(bf16(high + img) - low)                                                [ref: color_fix.py:122-184]
-__global__ __launch_bounds__(256) void wavelet_level_kernel(const bf16* __restrict__ img, bf16* __restrict__ low,
-                                                            bf16* __restrict__ high, int F, int H, int W, int r,
+template <typename T> __device__ __forceinline__ float ldv(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ float rnd(float v);          // rounding of the working dtype
+template <> __device__ __forceinline__ float rnd<bf16>(float v) { return rbf(v); }
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void wavelet_level_kernel(const T* __restrict__ img, T* __restrict__ low,
+                                                            T* __restrict__ high, int F, int H, int W, int r,
                                                             int first) {
     const long long n = (long long)F * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -24,7 +30,7 @@ __global__ __launch_bounds__(256) void wavelet_level_kernel(const bf16* __restri
         const long long t2 = i / W;
         const int y = (int)(t2 % H);
         const long long f = t2 / H;
-        const bf16* fr = img + f * H * W * 3;
+        const T* fr = img + f * H * W * 3;
         int ys[3], xs[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -37,27 +43,28 @@ __global__ __launch_bounds__(256) void wavelet_level_kernel(const bf16* __restri
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const float k = (dy == 1 ? 0.25f : 0.125f) * (dx == 1 ? 1.f : 0.5f);   // 1/16 2/16 1/16 ...
-                const bf16* p = fr + ((long long)ys[dy] * W + xs[dx]) * 3;
+                const T* p = fr + ((long long)ys[dy] * W + xs[dx]) * 3;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] += k * bf2f(p[c]);
+                for (int c = 0; c < 3; ++c) acc[c] += k * ldv(p + c);
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float lo = rbf(acc[c]);
-            low[i * 3 + c] = f2bf(lo);
+            const float lo = rnd<T>(acc[c]);
+            low[i * 3 + c] = (T)lo;
             if (high) {
-                const float h0 = first ? 0.f : bf2f(high[i * 3 + c]);
-                high[i * 3 + c] = f2bf(rbf(h0 + bf2f(img[i * 3 + c])) - lo);
+                const float h0 = first ? 0.f : ldv(high + i * 3 + c);
+                high[i * 3 + c] = (T)(rnd<T>(h0 + ldv(img + i * 3 + c)) - lo);
             }
         }
     }
 }
 
 // out = clamp(bf16(high + low), -1, 1)                                              [ref: color_fix.py:241-246]
-__global__ __launch_bounds__(256) void wavelet_merge_kernel(const bf16* __restrict__ high, const bf16* __restrict__ low,
-                                                            bf16* __restrict__ out, long long n) {
+template <typename T>
+__global__ __launch_bounds__(256) void wavelet_merge_kernel(const T* __restrict__ high, const T* __restrict__ low,
+                                                            T* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = f2bf(fminf(fmaxf(rbf(bf2f(high[i]) + bf2f(low[i])), -1.f), 1.f));
+        out[i] = (T)fminf(fmaxf(rnd<T>(ldv(high + i) + ldv(low + i)), -1.f), 1.f);
 }
 
 // ----------------------------------------------------------------------------- per-(frame, channel) moments
@@ -188,6 +195,132 @@ __global__ __launch_bounds__(256) void lab_to_rgb_kernel(const float* __restrict
     }
 }
 
+// ----------------------------------------------------------------------------- HSV saturation match
+__device__ __forceinline__ float unit01(float v) { return fminf(fmaxf((v + 1.f) * 0.5f, 0.f), 1.f); }
+
+__device__ __forceinline__ float sat_of(float r, float g, float b) {
+    const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+    return mx > 1e-10f ? (mx - mn) / fmaxf(mx, 1e-10f) : 0.f;
+}
+
+// x bf16 [n,3] in [-1,1] -> planar fp32 hsv[3][n] of clamp((x+1)/2, 0, 1)          [ref: color_fix.py:558-563,606-641]
+// (equal maxima: the reference's masked assignments run r, g, b in turn, so b wins over g wins over r)
+__global__ __launch_bounds__(256) void rgb_to_hsv_kernel(const bf16* __restrict__ x, float* __restrict__ hsv, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float r = unit01(bf2f(x[i * 3])), g = unit01(bf2f(x[i * 3 + 1])), b = unit01(bf2f(x[i * 3 + 2]));
+        const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b)), rng = mx - mn;
+        float h = 0.f;
+        if (rng > 1e-10f) {
+            if (mx == r) { const float q = (g - b) / rng; h = q - 6.f * floorf(q / 6.f); }
+            if (mx == g) h = (b - r) / rng + 2.f;
+            if (mx == b) h = (r - g) / rng + 4.f;
+        }
+        hsv[i] = h / 6.f;
+        hsv[n + i] = mx > 1e-10f ? rng / fmaxf(mx, 1e-10f) : 0.f;
+        hsv[2 * n + i] = mx;
+    }
+}
+
+struct HueBins { float thr[13]; float wrap; int pass; };   // thr[k] = fp32(k/12); pass 0: bins 0..10 (+wrap into 0), 1: bin 11
+
+__device__ __forceinline__ int hue_bin(float h, const HueBins& hb) {
+    if (hb.pass == 0) {
+        if (h >= hb.wrap) return 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+            if (h >= hb.thr[k] && h < hb.thr[k + 1]) return k;
+        return 15;
+    }
+    return (h >= hb.thr[11] && h < hb.thr[12]) ? 11 : 15;
+}
+
+// key = (hue bin << 32) | bits(s)  (s >= 0: its bit pattern orders like its value); counts per bin
+__global__ __launch_bounds__(256) void hue_keys_kernel(const float* __restrict__ h, const float* __restrict__ sv,
+                                                       unsigned long long* __restrict__ keys, int* __restrict__ idx,
+                                                       unsigned* __restrict__ counts, long long n, HueBins hb) {
+    __shared__ unsigned lc[16];
+    if (threadIdx.x < 16) lc[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = hue_bin(h[i], hb);
+        keys[i] = ((unsigned long long)b << 32) | __float_as_uint(sv[i]);
+        if (idx) idx[i] = (int)i;
+        atomicAdd(&lc[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
+}
+
+// rank r of a content pixel inside its bin -> reference quantile: r itself for equal counts, else
+// long(linspace(0, 1, n_src)[r] * (n_ref - 1)) with torch's fp32 linspace (two-sided, step = 1/(n-1))
+__global__ __launch_bounds__(256) void hue_map_kernel(const unsigned long long* __restrict__ ckeys, const int* __restrict__ cidx,
+                                                      const unsigned long long* __restrict__ skeys,
+                                                      const unsigned* __restrict__ ccnt, const unsigned* __restrict__ scnt,
+                                                      float* __restrict__ out, long long n, int min_pixels) {
+    __shared__ long long cstart[16], sstart[16];
+    if (threadIdx.x == 0) {
+        long long a = 0, b = 0;
+        for (int k = 0; k < 16; ++k) { cstart[k] = a; sstart[k] = b; a += ccnt[k]; b += scnt[k]; }
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(ckeys[i] >> 32);
+        if (b > 11) continue;
+        const long long ns = ccnt[b], nr = scnt[b];
+        if (ns <= min_pixels || nr <= min_pixels) continue;
+        const long long r = i - cstart[b];
+        long long j = r;
+        if (ns != nr) {
+            const float step = __fdiv_rn(1.f, (float)(ns - 1));
+            const float q = r < ns / 2 ? __fmul_rn(step, (float)r) : __fsub_rn(1.f, __fmul_rn(step, (float)(ns - r - 1)));
+            j = (long long)__fmul_rn(q, (float)(nr - 1));
+            j = j < 0 ? 0 : (j > nr - 1 ? nr - 1 : j);
+        }
+        out[cidx[i]] = __uint_as_float((unsigned)(skeys[sstart[b] + j] & 0xffffffffull));
+    }
+}
+
+// (h, s, v) -> rgb, clamp, *2-1, stored as T                                          [ref: color_fix.py:583-596,644-687]
+template <typename T>
+__global__ __launch_bounds__(256) void hsv_to_rgb_kernel(const float* __restrict__ h, const float* __restrict__ s_,
+                                                         const float* __restrict__ v_, T* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float h6 = h[i] * 6.f, s = s_[i], v = v_[i];
+        const float fl = floorf(h6), f = h6 - fl;
+        const int k = ((int)fl) % 6;
+        const float p = v * (1.f - s), q = v * (1.f - s * f), t = v * (1.f - s * (1.f - f));
+        float r, g, b;
+        switch (k) {
+            case 0: r = v; g = t; b = p; break;
+            case 1: r = q; g = v; b = p; break;
+            case 2: r = p; g = v; b = t; break;
+            case 3: r = p; g = q; b = v; break;
+            case 4: r = t; g = p; b = v; break;
+            default: r = v; g = p; b = q; break;
+        }
+        const float c[3] = {r, g, b};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) y[i * 3 + e] = (T)(fminf(fmaxf(c[e], 0.f), 1.f) * 2.f - 1.f);
+    }
+}
+
+// wavelet_adaptive blend: w = sigmoid(5((sat(c) - sat(s)) - 0.15)) * [sat(wav) - sat(s) > 0.075];
+// out = bf16(wav (1 - w) + hsv w)                                                     [ref: color_fix.py:805-833,846-860]
+__global__ __launch_bounds__(256) void sat_blend_kernel(const bf16* __restrict__ c, const bf16* __restrict__ s_,
+                                                        const float* __restrict__ wav, const float* __restrict__ hsv,
+                                                        bf16* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float cs = sat_of(unit01(bf2f(c[i * 3])), unit01(bf2f(c[i * 3 + 1])), unit01(bf2f(c[i * 3 + 2])));
+        const float ss = sat_of(unit01(bf2f(s_[i * 3])), unit01(bf2f(s_[i * 3 + 1])), unit01(bf2f(s_[i * 3 + 2])));
+        const float ws = sat_of(unit01(wav[i * 3]), unit01(wav[i * 3 + 1]), unit01(wav[i * 3 + 2]));
+        float w = 1.f / (1.f + expf(-(5.f * ((cs - ss) - 0.15f))));
+        w = (ws - ss) > 0.075f ? w : 0.f;
+        w = fminf(fmaxf(w, 0.f), 1.f);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) out[i * 3 + e] = f2bf(wav[i * 3 + e] * (1.f - w) + hsv[i * 3 + e] * w);
+    }
+}
+
 inline int grid_1d(long long n) {
     long long g = (n + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
@@ -201,20 +334,28 @@ inline int strips(long long P) {
 }  // namespace
 
 extern "C" int svr2_wavelet_level(const void* img, void* low, void* high, int32_t F, int32_t H, int32_t W, int32_t radius,
-                                  int32_t first, void* stream) {
+                                  int32_t first, int32_t is_f32, void* stream) {
     SVR2_CHECK(img && low, SVR2_E_ARG, "svr2_wavelet_level: null pointer");
     SVR2_CHECK(F > 0 && H > 0 && W > 0 && radius >= 1, SVR2_E_SHAPE, "svr2_wavelet_level: bad shape");
     const long long n = (long long)F * H * W;
-    hipLaunchKernelGGL(wavelet_level_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)img, (bf16*)low,
-                       (bf16*)high, F, H, W, radius, first);
+    if (is_f32)
+        hipLaunchKernelGGL(wavelet_level_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const float*)img,
+                           (float*)low, (float*)high, F, H, W, radius, first);
+    else
+        hipLaunchKernelGGL(wavelet_level_kernel<bf16>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)img,
+                           (bf16*)low, (bf16*)high, F, H, W, radius, first);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
 
-extern "C" int svr2_wavelet_merge(const void* high, const void* low, void* out, int64_t n, void* stream) {
+extern "C" int svr2_wavelet_merge(const void* high, const void* low, void* out, int64_t n, int32_t is_f32, void* stream) {
     SVR2_CHECK(high && low && out && n > 0, SVR2_E_ARG, "svr2_wavelet_merge: bad argument");
-    hipLaunchKernelGGL(wavelet_merge_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)high,
-                       (const bf16*)low, (bf16*)out, (long long)n);
+    if (is_f32)
+        hipLaunchKernelGGL(wavelet_merge_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const float*)high,
+                           (const float*)low, (float*)out, (long long)n);
+    else
+        hipLaunchKernelGGL(wavelet_merge_kernel<bf16>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)high,
+                           (const bf16*)low, (bf16*)out, (long long)n);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
@@ -286,6 +427,101 @@ extern "C" int svr2_lab_to_rgb(const float* L_content, const float* L_matched, c
     SVR2_CHECK(L_content && a && b && y && n > 0, SVR2_E_ARG, "svr2_lab_to_rgb: bad argument");
     hipLaunchKernelGGL(lab_to_rgb_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, L_content, L_matched, a, b,
                        luminance_weight, (bf16*)y, (long long)n);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_rgb_to_hsv(const void* x, float* hsv, int64_t n, void* stream) {
+    SVR2_CHECK(x && hsv && n > 0, SVR2_E_ARG, "svr2_rgb_to_hsv: bad argument");
+    hipLaunchKernelGGL(rgb_to_hsv_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, hsv,
+                       (long long)n);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+namespace {
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t hue_tmp_bytes(size_t n) {
+    size_t t1 = 0, t2 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t1, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (const int*)nullptr, (int*)nullptr, n, 0, 36);
+    (void)rocprim::radix_sort_keys(nullptr, t2, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0, 36);
+    return up256(t1 > t2 ? t1 : t2);
+}
+}  // namespace
+
+/* workspace of svr2_hue_sat_match: keys in/out for both images, indices in/out, counters, rocPRIM scratch */
+extern "C" int64_t svr2_hue_sat_match_ws_bytes(int64_t n) {
+    if (n <= 0 || n >= (1ll << 31)) return 0;
+    return (int64_t)(4 * up256((size_t)n * 8) + 2 * up256((size_t)n * 4) + 256 + hue_tmp_bytes((size_t)n));
+}
+
+/* out = content saturation with, per 30-degree hue bin holding more than min_pixels pixels in both images, the style
+ * saturation distribution moved onto the content ranks; bin 0 also takes the hues >= 11/12, which bin 11 then
+ * overwrites [ref: color_fix.py:690-757].  hsv_c / hsv_s: planar fp32 [3][n] from svr2_rgb_to_hsv; thresholds:
+ * 14 floats = fp32(k/12) for k = 0..12 and fp32(1 - 1/12). */
+extern "C" int svr2_hue_sat_match(const float* hsv_c, const float* hsv_s, float* out, int64_t n, const float* thresholds,
+                                  int32_t min_pixels, void* workspace, int64_t ws_bytes, void* stream) {
+    SVR2_CHECK(hsv_c && hsv_s && out && thresholds && workspace, SVR2_E_ARG, "svr2_hue_sat_match: null pointer");
+    SVR2_CHECK(n > 0 && n < (1ll << 31), SVR2_E_SHAPE, "svr2_hue_sat_match: n out of range");
+    SVR2_CHECK(ws_bytes >= svr2_hue_sat_match_ws_bytes(n), SVR2_E_ARG, "svr2_hue_sat_match: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t k8 = up256((size_t)n * 8), k4 = up256((size_t)n * 4);
+    char* w = (char*)workspace;
+    unsigned long long* ck_in = (unsigned long long*)w;
+    unsigned long long* ck_out = (unsigned long long*)(w + k8);
+    unsigned long long* sk_in = (unsigned long long*)(w + 2 * k8);
+    unsigned long long* sk_out = (unsigned long long*)(w + 3 * k8);
+    int* ix_in = (int*)(w + 4 * k8);
+    int* ix_out = (int*)(w + 4 * k8 + k4);
+    unsigned* counts = (unsigned*)(w + 4 * k8 + 2 * k4);          // [2][16]
+    void* tmp = w + 4 * k8 + 2 * k4 + 256;
+    const size_t tcap = (size_t)ws_bytes - (4 * k8 + 2 * k4 + 256);
+    SVR2_CHECK(hipMemcpyAsync(out, hsv_c + n, (size_t)n * 4, hipMemcpyDeviceToDevice, s) == hipSuccess, SVR2_E_LAUNCH,
+               "svr2_hue_sat_match: copy failed");
+    HueBins hb;
+    for (int k = 0; k < 13; ++k) hb.thr[k] = thresholds[k];
+    hb.wrap = thresholds[13];
+    for (int pass = 0; pass < 2; ++pass) {
+        hb.pass = pass;
+        SVR2_CHECK(hipMemsetAsync(counts, 0, 128, s) == hipSuccess, SVR2_E_LAUNCH, "svr2_hue_sat_match: memset failed");
+        hipLaunchKernelGGL(hue_keys_kernel, dim3(grid_1d(n)), dim3(256), 0, s, hsv_c, hsv_c + n, ck_in, ix_in, counts,
+                           (long long)n, hb);
+        hipLaunchKernelGGL(hue_keys_kernel, dim3(grid_1d(n)), dim3(256), 0, s, hsv_s, hsv_s + n, sk_in, (int*)nullptr,
+                           counts + 16, (long long)n, hb);
+        size_t tb = tcap;
+        hipError_t e = rocprim::radix_sort_pairs(tmp, tb, (const unsigned long long*)ck_in, ck_out, (const int*)ix_in, ix_out,
+                                                 (size_t)n, 0, 36, s);
+        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "svr2_hue_sat_match: radix_sort_pairs failed: %s", hipGetErrorString(e));
+        tb = tcap;
+        e = rocprim::radix_sort_keys(tmp, tb, (const unsigned long long*)sk_in, sk_out, (size_t)n, 0, 36, s);
+        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "svr2_hue_sat_match: radix_sort_keys failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(hue_map_kernel, dim3(grid_1d(n)), dim3(256), 0, s, (const unsigned long long*)ck_out,
+                           (const int*)ix_out, (const unsigned long long*)sk_out, (const unsigned*)counts,
+                           (const unsigned*)(counts + 16), out, (long long)n, min_pixels);
+    }
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_hsv_to_rgb(const float* h, const float* s_, const float* v, void* y, int64_t n, int32_t out_f32,
+                               void* stream) {
+    SVR2_CHECK(h && s_ && v && y && n > 0, SVR2_E_ARG, "svr2_hsv_to_rgb: bad argument");
+    if (out_f32)
+        hipLaunchKernelGGL(hsv_to_rgb_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, h, s_, v, (float*)y,
+                           (long long)n);
+    else
+        hipLaunchKernelGGL(hsv_to_rgb_kernel<bf16>, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, h, s_, v, (bf16*)y,
+                           (long long)n);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_sat_blend(const void* content, const void* style, const float* wav, const float* hsv, void* out, int64_t n,
+                              void* stream) {
+    SVR2_CHECK(content && style && wav && hsv && out && n > 0, SVR2_E_ARG, "svr2_sat_blend: bad argument");
+    hipLaunchKernelGGL(sat_blend_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)content,
+                       (const bf16*)style, wav, hsv, (bf16*)out, (long long)n);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

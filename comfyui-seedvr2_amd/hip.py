@@ -66,7 +66,7 @@ class QkvPrepDesc(C.Structure):
 
 _lib = None
 _zero_pages = {}
-_INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes")
+_INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes", "svr2_hue_sat_match_ws_bytes")
 
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -77,6 +77,7 @@ EXPORTS = [
     "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
     "svr2_wavelet_level", "svr2_wavelet_merge", "svr2_adain_ws_bytes", "svr2_adain", "svr2_rgb_to_lab",
     "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
+    "svr2_rgb_to_hsv", "svr2_hue_sat_match_ws_bytes", "svr2_hue_sat_match", "svr2_hsv_to_rgb", "svr2_sat_blend",
 ]
 
 
@@ -531,15 +532,17 @@ def crop_to_unit(x: torch.Tensor, h: int, w: int, to_unit: bool, out: Optional[t
 
 
 # ----------------------------------------------------------------------------------------------- colour correction
-def _frames3(t: torch.Tensor, name: str):
-    _bf16c(t, name)
+def _frames3(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    if t.dtype != dtype or not t.is_cuda:
+        raise HipError(f"{name}: expected a {dtype} device tensor, got {t.dtype} on {t.device}")
     if t.dim() != 4 or t.shape[3] != 3 or not t.is_contiguous():
-        raise HipError(f"{name}: expected contiguous bf16 [F,H,W,3]")
+        raise HipError(f"{name}: expected contiguous [F,H,W,3]")
 
 
 def wavelet_decomposition(x: torch.Tensor, levels: int = 5, want_high: bool = True):
-    """[F,H,W,3] bf16 -> (high, low) of the reference's dilated-Gaussian pyramid (high is None if not wanted)."""
-    _frames3(x, "wavelet.x")
+    """[F,H,W,3] bf16 (or fp32) -> (high, low) of the reference's dilated-Gaussian pyramid (high None if not wanted)."""
+    f32 = x.dtype == torch.float32
+    _frames3(x, "wavelet.x", x.dtype if f32 else torch.bfloat16)
     Fr, H, W, _ = x.shape
     high = torch.empty_like(x) if want_high else None
     img = x
@@ -547,18 +550,20 @@ def wavelet_decomposition(x: torch.Tensor, levels: int = 5, want_high: bool = Tr
         radius = min(2 ** i, max(1, min(H, W) // 8))
         low = torch.empty_like(x)
         _check(lib().svr2_wavelet_level(_p(img), _p(low), _p(high), C.c_int32(Fr), C.c_int32(H), C.c_int32(W),
-                                        C.c_int32(radius), C.c_int32(1 if i == 0 else 0), _stream()), "svr2_wavelet_level")
+                                        C.c_int32(radius), C.c_int32(1 if i == 0 else 0), C.c_int32(int(f32)), _stream()),
+               "svr2_wavelet_level")
         img = low
     return high, img
 
 
 def wavelet_reconstruction(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
-    if content.shape != style.shape:
-        raise HipError("wavelet_reconstruction: content and style must have the same shape")
+    if content.shape != style.shape or content.dtype != style.dtype:
+        raise HipError("wavelet_reconstruction: content and style must have the same shape and dtype")
     high, _ = wavelet_decomposition(content, want_high=True)
     _, low = wavelet_decomposition(style, want_high=False)
     out = torch.empty_like(content)
-    _check(lib().svr2_wavelet_merge(_p(high), _p(low), _p(out), C.c_int64(out.numel()), _stream()), "svr2_wavelet_merge")
+    _check(lib().svr2_wavelet_merge(_p(high), _p(low), _p(out), C.c_int64(out.numel()),
+                                    C.c_int32(int(content.dtype == torch.float32)), _stream()), "svr2_wavelet_merge")
     return out
 
 
@@ -598,12 +603,64 @@ def lab_color_transfer(content: torch.Tensor, style: torch.Tensor, luminance_wei
     return out
 
 
-COLOR_METHODS = {"lab": lab_color_transfer, "wavelet": wavelet_reconstruction, "adain": adain}
+_HUE_THRESHOLDS = None
+
+
+def _hue_thresholds():
+    """fp32(k * (1/12)) for k = 0..12 and fp32(1 - 1/12): the bin edges the reference compares fp32 hues against
+    (Python doubles cast to the tensor dtype) [ref: color_fix.py:704-719]."""
+    global _HUE_THRESHOLDS
+    if _HUE_THRESHOLDS is None:
+        import numpy as np
+        bw = 1.0 / 12
+        vals = [np.float32(k * bw) for k in range(12)] + [np.float32(12 * bw), np.float32(1.0 - bw)]
+        _HUE_THRESHOLDS = (C.c_float * 14)(*[float(v) for v in vals])
+    return _HUE_THRESHOLDS
+
+
+def hsv_saturation_match(content: torch.Tensor, style: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
+    """Hue-conditional saturation histogram matching: content keeps its hue and value, its saturation takes the style's
+    distribution per 30-degree hue bin."""
+    _frames3(content, "hsv.content"); _frames3(style, "hsv.style")
+    if content.shape != style.shape:
+        raise HipError("hsv: content and style must have the same shape")
+    n = content.numel() // 3
+    dev = content.device
+    hc = torch.empty(3, n, dtype=torch.float32, device=dev)
+    hs = torch.empty(3, n, dtype=torch.float32, device=dev)
+    _check(lib().svr2_rgb_to_hsv(_p(content), _p(hc), C.c_int64(n), _stream()), "svr2_rgb_to_hsv")
+    _check(lib().svr2_rgb_to_hsv(_p(style), _p(hs), C.c_int64(n), _stream()), "svr2_rgb_to_hsv")
+    nws = int(lib().svr2_hue_sat_match_ws_bytes(C.c_int64(n)))
+    if nws <= 0:
+        raise HipError("hsv: batch too large for one histogram match")
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    ms = torch.empty(n, dtype=torch.float32, device=dev)
+    _check(lib().svr2_hue_sat_match(_p(hc), _p(hs), _p(ms), C.c_int64(n), _hue_thresholds(), C.c_int32(100), _p(ws),
+                                    C.c_int64(nws), _stream()), "svr2_hue_sat_match")
+    out = torch.empty(content.shape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+    _check(lib().svr2_hsv_to_rgb(_p(hc[0]), _p(ms), _p(hc[2]), _p(out), C.c_int64(n), C.c_int32(int(out_f32)), _stream()),
+           "svr2_hsv_to_rgb")
+    return out
+
+
+def wavelet_adaptive(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    """Wavelet base (in fp32 like the reference), HSV saturation correction blended into the oversaturated regions."""
+    _frames3(content, "wavelet_adaptive.content"); _frames3(style, "wavelet_adaptive.style")
+    wav = wavelet_reconstruction(content.float(), style.float())
+    hsv = hsv_saturation_match(content, style, out_f32=True)
+    out = torch.empty_like(content)
+    _check(lib().svr2_sat_blend(_p(content), _p(style), _p(wav), _p(hsv), _p(out), C.c_int64(content.numel() // 3),
+                                _stream()), "svr2_sat_blend")
+    return out
+
+
+COLOR_METHODS = {"lab": lab_color_transfer, "wavelet": wavelet_reconstruction, "adain": adain,
+                 "hsv": hsv_saturation_match, "wavelet_adaptive": wavelet_adaptive}
 
 
 def color_correct(sample: torch.Tensor, input_video: torch.Tensor, method: str) -> torch.Tensor:
     """Phase-4 colour correction of a decoded batch [T,H,W,3] in [-1,1] against the transformed input of the same frames
-    [ref: src/core/generation_phases.py:1290-1304].  'hsv' and 'wavelet_adaptive' are not implemented."""
+    [ref: src/core/generation_phases.py:1290-1304]."""
     if method not in COLOR_METHODS:
-        raise HipError(f"color_correction '{method}' is not implemented (available: none, {', '.join(COLOR_METHODS)})")
+        raise HipError(f"unknown color_correction '{method}' (available: none, {', '.join(COLOR_METHODS)})")
     return COLOR_METHODS[method](sample, input_video)

@@ -261,8 +261,8 @@ int svr2_crop_to_unit(const void* in, void* out, int32_t T, int32_t Hp, int32_t 
  * svr2_lab_to_rgb: L = Lc*lw + Lm*(1-lw) (Lm may be NULL), lab -> rgb -> bf16 [-1,1]   [ref: color_fix.py:335-361,414-470]
  */
 int svr2_wavelet_level(const void* img, void* low, void* high, int32_t F, int32_t H, int32_t W, int32_t radius,
-                       int32_t first, void* stream);
-int svr2_wavelet_merge(const void* high, const void* low, void* out, int64_t n, void* stream);
+                       int32_t first, int32_t is_f32, void* stream);
+int svr2_wavelet_merge(const void* high, const void* low, void* out, int64_t n, int32_t is_f32, void* stream);
 int64_t svr2_adain_ws_bytes(int32_t F, int64_t P);
 int svr2_adain(const void* content, const void* style, void* out, int32_t F, int64_t P, void* workspace, void* stream);
 int svr2_rgb_to_lab(const void* x, float* lab, int64_t n, void* stream);
@@ -271,6 +271,23 @@ int svr2_hist_match(const float* source, const float* reference, float* out, int
                     int64_t ws_bytes, void* stream);
 int svr2_lab_to_rgb(const float* L_content, const float* L_matched, const float* a, const float* b,
                     float luminance_weight, void* y, int64_t n, void* stream);
+/* 'hsv' and 'wavelet_adaptive' [ref: color_fix.py:516-860] (is_f32 above: the adaptive mode runs its wavelet in fp32).
+ * svr2_rgb_to_hsv: planar fp32 hsv[3][n] of clamp((x+1)/2, 0, 1); equal maxima resolve b over g over r like the
+ *   reference's masked assignments.
+ * svr2_hue_sat_match: content saturation with, per 30-degree hue bin holding more than min_pixels pixels in both
+ *   images, the style saturation distribution moved onto the content ranks (unequal counts: reference quantile
+ *   long(linspace(0,1,n_src)[rank] * (n_ref - 1))); bin 0 also takes hues >= 11/12, which bin 11 then overwrites.
+ *   thresholds (host): fp32(k/12) for k = 0..12, then fp32(1 - 1/12).
+ * svr2_hsv_to_rgb: (h, s, v) -> rgb, clamp, *2-1, stored as bf16 or fp32.
+ * svr2_sat_blend: out = wav (1 - w) + hsv w, w = sigmoid(5 ((sat(content) - sat(style)) - 0.15)) where
+ *   sat(wav) - sat(style) > 0.075, else 0. */
+int svr2_rgb_to_hsv(const void* x, float* hsv, int64_t n, void* stream);
+int64_t svr2_hue_sat_match_ws_bytes(int64_t n);
+int svr2_hue_sat_match(const float* hsv_c, const float* hsv_s, float* out, int64_t n, const float* thresholds,
+                       int32_t min_pixels, void* workspace, int64_t ws_bytes, void* stream);
+int svr2_hsv_to_rgb(const float* h, const float* s, const float* v, void* y, int64_t n, int32_t out_f32, void* stream);
+int svr2_sat_blend(const void* content, const void* style, const float* wav, const float* hsv, void* out, int64_t n,
+                   void* stream);
 
 #ifdef __cplusplus
 }

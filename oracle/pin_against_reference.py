@@ -350,6 +350,7 @@ def main():
     base = torch.rand(2, 3, 6, 8, generator=g)
     style32 = torch.nn.functional.interpolate(base, size=(40, 56), mode="bicubic").clamp(0, 1) * 2 - 1
     content32 = (style32 * 0.8 + 0.1 + 0.05 * torch.randn(2, 3, 40, 56, generator=g)).clamp(-1, 1)
+    content32[:, 0] = (content32[:, 0] * 1.3).clamp(-1, 1)      # oversaturate one channel: exercises the adaptive blend
     for tag, dt, tol in (("f32", torch.float32, 1e-6), ("bf16", torch.bfloat16, 0.0)):
         c, s_ = content32.to(dt), style32.to(dt)
         r_ad = cf.adaptive_instance_normalization(c.clone(), s_.clone())
@@ -359,8 +360,14 @@ def main():
         r_lab = cf.lab_color_transfer(c.clone(), s_.clone(), _Dbg(), luminance_weight=0.8)
         check(f"G12 lab_color_transfer {tag}", ocol.lab_color_transfer(c.clone(), s_.clone()).float(), r_lab.float(),
               2e-6 if dt == torch.float32 else 0.0)
+        r_hsv = cf.hsv_saturation_histogram_match(c.clone(), s_.clone(), _Dbg())
+        check(f"G12 hsv_saturation_histogram_match {tag}", ocol.hsv_saturation_histogram_match(c.clone(), s_.clone()).float(),
+              r_hsv.float(), 2e-6 if dt == torch.float32 else 0.0)
+        r_wa = cf.wavelet_adaptive_color_correction(c.clone(), s_.clone(), _Dbg())
+        check(f"G12 wavelet_adaptive {tag}", ocol.wavelet_adaptive_color_correction(c.clone(), s_.clone()).float(),
+              r_wa.float(), 2e-6 if dt == torch.float32 else 0.0)
         ct.update({f"G12.{tag}.content": c, f"G12.{tag}.style": s_, f"G12.{tag}.adain": r_ad, f"G12.{tag}.wavelet": r_wv,
-                   f"G12.{tag}.lab": r_lab})
+                   f"G12.{tag}.lab": r_lab, f"G12.{tag}.hsv": r_hsv, f"G12.{tag}.wavelet_adaptive": r_wa})
     lab = cf._rgb_to_lab_batch((style32 + 1) / 2, torch.device("cpu"), torch.tensor(ocol._RGB2XYZ), ocol.EPS, ocol.KAPPA)
     check("G12 rgb->lab", ocol.rgb_to_lab((style32 + 1) / 2), lab, 1e-5)
     ct["G12.lab_of_style"] = lab

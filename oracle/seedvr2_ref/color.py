@@ -4,6 +4,9 @@ Follows /root/reference/src/utils/color_fix.py:
   calc_mean_std :72-91, adaptive_instance_normalization :94-119, wavelet_blur :122-157,
   wavelet_decomposition :160-184, wavelet_reconstruction :187-246, lab_color_transfer :249-365,
   _rgb_to_lab_batch :368-411, _lab_to_rgb_batch :414-470, _histogram_matching_channel :473-513,
+  hsv_saturation_histogram_match :516-603, _rgb_to_hsv_batch :606-641, _hsv_to_rgb_batch :644-687,
+  _hue_conditional_saturation_match :690-733, _histogram_match_1d :736-757,
+  wavelet_adaptive_color_correction :760-843, _get_saturation_map :846-860,
 and the call site src/core/generation_phases.py:1290-1304 (content = decoded sample, style = transformed input,
 both [T,3,H,W] in [-1,1] in the compute dtype - bf16 on the reference's GPU/CPU path).
 
@@ -120,7 +123,99 @@ def lab_color_transfer(content: torch.Tensor, style: torch.Tensor, luminance_wei
     return lab_to_rgb(torch.stack([L, a, b], dim=1)).mul(2.0).sub(1.0).to(dtype)
 
 
-METHODS = {"lab": lab_color_transfer, "wavelet": wavelet_reconstruction, "adain": adaptive_instance_normalization}
+def rgb_to_hsv(rgb: torch.Tensor) -> torch.Tensor:
+    """[B,3,H,W] fp32 in [0,1] -> (h, s, v), all in [0,1]  [ref: color_fix.py:606-641]."""
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    maxc, minc = torch.max(rgb, dim=1)[0], torch.min(rgb, dim=1)[0]
+    rng = maxc - minc
+    nz = torch.where(rng > 1e-10, rng, torch.ones_like(rng))
+    h = torch.zeros_like(maxc)
+    m = (maxc == r) & (rng > 1e-10)
+    h[m] = ((g[m] - b[m]) / nz[m]) % 6.0
+    m = (maxc == g) & (rng > 1e-10)
+    h[m] = ((b[m] - r[m]) / nz[m]) + 2.0
+    m = (maxc == b) & (rng > 1e-10)
+    h[m] = ((r[m] - g[m]) / nz[m]) + 4.0
+    h.div_(6.0)
+    s = torch.where(maxc > 1e-10, rng / torch.clamp(maxc, min=1e-10), torch.zeros_like(maxc))
+    return torch.stack([h, s, maxc], dim=1)
+
+
+def hsv_to_rgb(hsv: torch.Tensor) -> torch.Tensor:
+    """[ref: color_fix.py:644-687]"""
+    h, s, v = hsv[:, 0].mul(6.0), hsv[:, 1], hsv[:, 2]
+    i = torch.floor(h).long() % 6
+    f = h - torch.floor(h)
+    p, q, t = v * (1.0 - s), v * (1.0 - s * f), v * (1.0 - s * (1.0 - f))
+    r, g, b = torch.zeros_like(v), torch.zeros_like(v), torch.zeros_like(v)
+    for k, (rr, gg, bb) in enumerate(((v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q))):
+        m = i == k
+        r[m], g[m], b[m] = rr[m], gg[m], bb[m]
+    return torch.stack([r, g, b], dim=1)
+
+
+def histogram_match_1d(source: torch.Tensor, reference: torch.Tensor) -> torch.Tensor:
+    """[ref: color_fix.py:736-757]; unequal sizes: reference quantile long(linspace(0,1,n)[i] * (n_ref - 1))."""
+    ss, si = torch.sort(source)
+    rs, _ = torch.sort(reference)
+    if ss.numel() != rs.numel():
+        q = torch.linspace(0, 1, ss.numel())
+        rs = rs[(q * (rs.numel() - 1)).long().clamp_(0, rs.numel() - 1)]
+    out = torch.empty_like(source)
+    out.scatter_(0, si, rs)
+    return out
+
+
+def hue_conditional_saturation_match(ch, cs, sh, ss_, num_bins: int = 12, min_pixels: int = 100) -> torch.Tensor:
+    """Saturation histogram match per 30-degree hue bin; bin 0 also takes the wrap-around hues >= 11/12 (which bin 11
+    then overwrites) [ref: color_fix.py:690-733]."""
+    bw = 1.0 / num_bins
+    out = cs.clone()
+    for k in range(num_bins):
+        lo, hi = k * bw, (k + 1) * bw
+        if k == 0:
+            cm = ((ch >= 0) & (ch < hi)) | (ch >= (1.0 - bw))
+            sm = ((sh >= 0) & (sh < hi)) | (sh >= (1.0 - bw))
+        else:
+            cm, sm = (ch >= lo) & (ch < hi), (sh >= lo) & (sh < hi)
+        a, b = cs[cm], ss_[sm]
+        if len(a) > min_pixels and len(b) > min_pixels:
+            out[cm] = histogram_match_1d(a, b)
+    return out
+
+
+def hsv_saturation_histogram_match(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    """[ref: color_fix.py:516-603]"""
+    dtype = content.dtype
+    c = rgb_to_hsv(content.float().add(1.0).mul(0.5).clamp(0.0, 1.0))
+    s = rgb_to_hsv(style.float().add(1.0).mul(0.5).clamp(0.0, 1.0))
+    ms = hue_conditional_saturation_match(c[:, 0], c[:, 1], s[:, 0], s[:, 1])
+    rgb = hsv_to_rgb(torch.stack([c[:, 0], ms, c[:, 2]], dim=1)).clamp_(0.0, 1.0)
+    return rgb.mul(2.0).sub(1.0).to(dtype)
+
+
+def saturation_map(x: torch.Tensor) -> torch.Tensor:
+    """[ref: color_fix.py:846-860]"""
+    rgb = x.add(1.0).mul(0.5).clamp(0.0, 1.0)
+    maxc, minc = torch.max(rgb, dim=1, keepdim=True)[0], torch.min(rgb, dim=1, keepdim=True)[0]
+    return torch.where(maxc > 1e-10, (maxc - minc) / torch.clamp(maxc, min=1e-10), torch.zeros_like(maxc))
+
+
+def wavelet_adaptive_color_correction(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    """Wavelet base, HSV saturation correction blended into the regions that are (and stay) oversaturated; everything
+    in fp32 (the reference promotes BEFORE the wavelet here, unlike 'lab')  [ref: color_fix.py:760-843]."""
+    dtype = content.dtype
+    c, s = content.float(), style.float()
+    wav = wavelet_reconstruction(c.clone(), s.clone())
+    hsv = hsv_saturation_histogram_match(c, s)
+    cs, ss_, ws = saturation_map(c), saturation_map(s), saturation_map(wav)
+    w = torch.sigmoid(5.0 * ((cs - ss_) - 0.15))
+    w = (w * ((ws - ss_) > 0.075).float()).clamp_(0.0, 1.0)
+    return (wav * (1.0 - w) + hsv * w).to(dtype)
+
+
+METHODS = {"lab": lab_color_transfer, "wavelet": wavelet_reconstruction, "adain": adaptive_instance_normalization,
+           "hsv": hsv_saturation_histogram_match, "wavelet_adaptive": wavelet_adaptive_color_correction}
 
 
 def color_correct(sample_thwc: torch.Tensor, input_thwc: torch.Tensor, method: str) -> torch.Tensor:

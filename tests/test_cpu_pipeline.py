@@ -128,7 +128,8 @@ def test_color_oracle_matches_reference_golden():
     for tag, tol in (("f32", 2e-5), ("bf16", 1.6e-2)):      # bf16: one ulp at |v| ~ 1 (conv accumulation order of the host)
         c, s_ = t[f"G12.{tag}.content"], t[f"G12.{tag}.style"]
         for name, fn in (("adain", ocol.adaptive_instance_normalization), ("wavelet", ocol.wavelet_reconstruction),
-                         ("lab", ocol.lab_color_transfer)):
+                         ("lab", ocol.lab_color_transfer), ("hsv", ocol.hsv_saturation_histogram_match),
+                         ("wavelet_adaptive", ocol.wavelet_adaptive_color_correction)):
             got = fn(c.clone(), s_.clone()).float()
             ref = t[f"G12.{tag}.{name}"].float()
             assert got.shape == ref.shape

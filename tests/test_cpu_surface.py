@@ -48,7 +48,7 @@ def test_node_inputs_and_loader_dicts(pkg, surface):
     with pytest.raises(NotImplementedError):
         N.SeedVR2LoadVAEModel.execute(decode_tiled=True)
     with pytest.raises(NotImplementedError):
-        N.SeedVR2VideoUpscaler.execute(torch.zeros(1, 8, 8, 3), dit_cfg, vae_cfg, color_correction="hsv", pipeline=object())
+        N.SeedVR2VideoUpscaler.execute(torch.zeros(1, 8, 8, 3), dit_cfg, vae_cfg, color_correction="bogus", pipeline=object())
 
 
 def test_runner_condition_matches_reference_semantics(pkg):
