@@ -116,17 +116,39 @@ def main(argv=None) -> int:
         if a.load_cap:
             frames = frames[:a.load_cap]
         devs = [d for d in (a.cuda_device or "0").split(",") if d != ""]
-        if len(devs) > 1:
-            raise SystemExit("multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N` "
-                             "(see parallel.py / INTEGRATION.md)")
-        dit_cfg, = pkg.nodes.SeedVR2LoadDiTModel.execute(model=a.dit_model, device=f"cuda:{devs[0]}")
-        vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(device=f"cuda:{devs[0]}")
+        world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+        if len(devs) > 1 and world == 1:
+            raise SystemExit(f"multi-GPU: launch one process per GPU, `python -m torch.distributed.run --nproc-per-node "
+                             f"{len(devs)} --master-addr 127.0.0.1 inference_cli.py ...` (frame segments + one RCCL "
+                             "neighbour exchange, parallel.py / INTEGRATION.md)")
+        dev = f"cuda:{devs[local % len(devs)] if world > 1 else devs[0]}"
+        dist = None
+        if world > 1:   # the reference's multi-GPU mode: one segment per rank [ref: inference_cli.py:1048-1209]
+            import torch.distributed as dist
+            torch.cuda.set_device(torch.device(dev))
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        dit_cfg, = pkg.nodes.SeedVR2LoadDiTModel.execute(model=a.dit_model, device=dev)
+        vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(device=dev)
         txt = pkg.weights.find_model_file("pos_emb.pt", a.model_dir) or os.path.join(here, "pos_emb.pt")
         text_pos = torch.load(txt, weights_only=True)
-        out, = pkg.nodes.SeedVR2VideoUpscaler.execute(
-            frames, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
-            a.temporal_overlap, a.prepend_frames, a.color_correction, a.input_noise_scale, a.latent_noise_scale,
-            text_pos=text_pos)
+
+        def run(seg, prepend):
+            return pkg.nodes.SeedVR2VideoUpscaler.execute(
+                seg, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
+                a.temporal_overlap, prepend, a.color_correction, a.input_noise_scale, a.latent_noise_scale,
+                text_pos=text_pos)[0]
+
+        if world > 1:   # rank 0 alone applies prepend_frames [ref: inference_cli.py:981-984]
+            out = pkg.parallel.upscale_distributed(
+                lambda seg: run(seg, a.prepend_frames if rank == 0 else 0).to(dev), frames, a.temporal_overlap, rank,
+                world, dist, a.batch_size)
+            dist.barrier()
+            dist.destroy_process_group()
+            if rank != 0:
+                return 0
+            out = out.cpu()
+        else:
+            out = run(frames, a.prepend_frames)
         outp = a.output or (os.path.splitext(a.input)[0] + "_upscaled" + (".png" if out.shape[0] == 1 else ""))
         save_frames(out, outp)
         dt = time.time() - t0

@@ -125,3 +125,18 @@ def gather_frames(frames: torch.Tensor, rank: int, world: int, dst: int = 0, dis
             dist.recv(buf, r)
             parts.append(buf)
     return torch.cat(parts, dim=0)
+
+
+def upscale_distributed(generate, frames: torch.Tensor, overlap: int, rank: int, world: int, dist=None,
+                        batch_size: int = 1, streaming: bool = True, gather_to: Optional[int] = 0):
+    """The reference's multi-GPU mode as one call per rank [ref: inference_cli.py:1048-1209]: rank r upscales its
+    segment of `frames` (all ranks hold the same LR clip) with `generate(segment_frames) -> [T', H, W, C]`, the segment
+    boundaries are cross-faded through the neighbour exchange, and (gather_to is not None) the finished frames are
+    collected on rank `gather_to`.  Returns the gathered clip on that rank (None elsewhere), or this rank's owned frames
+    when gather_to is None."""
+    s, e = segment_ranges(frames.shape[0], world, overlap, batch_size, streaming)[rank]
+    mine = generate(frames[s:e])
+    owned = exchange_and_blend(mine, overlap, rank, world, dist)
+    if gather_to is None:
+        return owned
+    return gather_frames(owned, rank, world, gather_to, dist)

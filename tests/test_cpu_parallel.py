@@ -43,10 +43,9 @@ def _worker(rank, world, port, total, overlap, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s, e = pkg.parallel.segment_ranges(total, world, overlap)[rank]
-        mine = _fake_upscale(torch.arange(s, e), rank)
-        owned = pkg.parallel.exchange_and_blend(mine, overlap, rank, world, dist)
-        full = pkg.parallel.gather_frames(owned, rank, world, 0, dist)
+        # every rank holds the whole LR clip (here: the frame ids); the driver segments, exchanges and gathers
+        full = pkg.parallel.upscale_distributed(lambda seg: _fake_upscale(seg, rank), torch.arange(total), overlap, rank,
+                                                world, dist)
         if rank == 0:
             q.put(full)
     finally:
