@@ -255,3 +255,50 @@ def test_runner_seam_and_node(pkg, gpu):
     out, = pkg.nodes.SeedVR2VideoUpscaler.execute(lr, {}, {}, 42, 32, 0, 5, False, 0, 1, "none", pipeline=pipe)
     assert out.dtype == torch.float32 and out.device.type == "cpu" and out.shape == (5, 32, 48, 3)
     assert out.min() >= 0 and out.max() <= 1
+
+
+def test_cli_from_checkpoint_files(pkg, gpu, tmp_path, monkeypatch):
+    """SURVEY 8f next-1, checkpoint ingestion end to end: full-size NaDiT-3B and VAE weights written as the reference's
+    files (fp16 .safetensors, reference key layout, the VAE attention under its deprecated diffusers names
+    query/key/value/proj_attn with 1x1-conv shaped weights) are found by name, loaded through the node loaders by the
+    CLI, and give the same pixels as a pipeline built directly from the bf16-rounded tensors."""
+    from safetensors.torch import save_file
+    dcfg, vcfg = pkg.dit.CFG_3B, pkg.vae.VAEConfig()
+    dsd = pkg.dit.synthetic_state_dict(dcfg, gpu, seed=31)
+    vsd = pkg.vae.synthetic_state_dict(vcfg, gpu, seed=32)
+    rename = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    vfile = {}
+    for k, v in vsd.items():
+        if ".attentions." in k:
+            for new, old in rename.items():
+                if f".{new}." in k:
+                    k = k.replace(f".{new}.", f".{old}.")
+                    if k.endswith(".weight"):
+                        v = v[:, :, None, None]                        # old blocks stored 1x1 convs
+        vfile[k] = v.to(torch.float16).cpu().contiguous()
+    mdir = tmp_path / "SEEDVR2"
+    mdir.mkdir()
+    save_file({k: v.to(torch.float16).cpu().contiguous() for k, v in dsd.items()}, str(mdir / pkg.weights.DEFAULT_DIT))
+    save_file(vfile, str(mdir / pkg.weights.DEFAULT_VAE))
+    txt = bf(torch.randn(58, 5120, generator=torch.Generator().manual_seed(33)) * 0.5)
+    torch.save(txt, str(mdir / "pos_emb.pt"))
+    lr = torch.rand(1, 24, 32, 3, generator=torch.Generator().manual_seed(34))
+    lr = (lr * 255).round() / 255
+    torch.save(lr, str(tmp_path / "in.pt"))
+    monkeypatch.setenv("SEEDVR2_MODEL_DIR", str(mdir))
+    out_path = str(tmp_path / "out.npy")
+    import importlib
+    cli = importlib.import_module(pkg.__name__ + ".inference_cli")
+    rc = cli.main([str(tmp_path / "in.pt"), "--resolution", "48", "--batch_size", "1", "--seed", "7",
+                                 "--color_correction", "lab", "--model_dir", str(mdir), "--output", out_path])
+    assert rc == 0
+    got = torch.from_numpy(np.load(out_path))
+    # the same weights, rounded the way the loader rounds them (fp16 file -> bf16), through the pipeline directly
+    rd = lambda t: t.to(torch.float16).to(torch.bfloat16)
+    dit = pkg.dit.NaDiTHip(dcfg, {k: rd(v) for k, v in dsd.items()}, gpu)
+    vae = pkg.vae.VideoVAEHip(vcfg, {k: rd(v) for k, v in vsd.items()}, gpu)
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    ref = pipe.generate(lr, resolution=48, batch_size=1, temporal_overlap=0, seed=7, color_correction="lab")
+    want = (ref.float().cpu().clamp(0, 1) * 255.0).to(torch.uint8)
+    assert got.shape == want.shape == (1, 48, 64, 3)
+    assert torch.equal(got, want)
