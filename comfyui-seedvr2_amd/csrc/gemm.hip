@@ -318,11 +318,21 @@ int launch(const KArgs& a, hipStream_t s) {
     // the other geometry for A/B runs.
     // Large problems go to the second-generation kernel (gemm2.hip: 256-row tiles, 128x64 per wave, BK 32,
     // 3-deep ring); SVR2_GEMM_V=1 keeps everything on this kernel for A/B runs.
-    static int ver = -1;
-    if (ver < 0) { const char* e = getenv("SVR2_GEMM_V"); ver = e ? atoi(e) : 2; }
+    const char* ev = getenv("SVR2_GEMM_V");     // read per call: tests switch kernels with it
+    const int ver = ev ? atoi(ev) : 2;
     const long long tiles2 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     // measured (profiles/r01_*): the 256x256x64 geometry wins by 16-20 % wherever N is a multiple of 256; for
     // N = 128 the 256x128x32 geometry is +3 % on 128-channel inputs and -18 % on 256-channel inputs.
+    // dense GEMMs with N % 256 == 0: the ping-pong kernel (gemm4.hip); SVR2_GEMM4=0 keeps them on gemm2 for A/B runs
+    // (long K loops only: its prologue fills two K-steps and the phases need a few steps to pay off; measured slower on
+    // the K = 256..512 GEMMs of the VAE)
+    // the row-gathered proj_out GEMM stays on gemm2: scattered rows make its DMA pieces cost the two A-streaming waves of a
+    // group more than a LOAD phase has - measured 535 vs 850 TFLOP/s)
+    if (AMODE == A_DENSE && a.N % 256 == 0 && a.K % 64 == 0 &&
+        ((a.K >= 1024 && tiles2 >= 384 && !a.a_rows) || (ver == 3 && a.K >= 128))) {
+        const char* e4 = getenv("SVR2_GEMM4");
+        if (!e4 || atoi(e4) != 0) return gemm4_launch(EPI, a, s);
+    }
     const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.cg.Cin <= 128 && a.N == 128);
     if (((ver == 2 && tiles2 >= 384 && v2_shape) || ver == 3) && a.K % 32 == 0)
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)

@@ -221,75 +221,7 @@ __global__ __launch_bounds__(Geo2<BN>::NT, 2) void gemm2_kernel(const KArgs a) {
     }
     __syncthreads();
 
-    if (EPI == SVR2_EPI_SWIGLU) {
-        // columns [16p, 16p+8) = gate, [16p+8, 16p+16) = in  ->  output columns [8p, 8p+8)
-        for (int c = tid; c < BM2 * (BN / 16); c += NT) {
-            const int row = c / (BN / 16), p = c % (BN / 16);
-            const int m = tile_row_to_m<AMODE, BM2>(a, tm, row), ncol = (n0 >> 1) + p * 8;
-            if (m >= a.M || (n0 + p * 16) >= a.N) continue;
-            const bf16x8 gv = *(const bf16x8*)(smem + row * G::EPI_LD + p * 32);
-            const bf16x8 iv = *(const bf16x8*)(smem + row * G::EPI_LD + p * 32 + 16);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = bf2f(gv[e]);
-                o[e] = f2bf(g / (1.f + __expf(-g)) * bf2f(iv[e]));
-            }
-            *(bf16x8*)(a.C + (long long)m * a.ldc + ncol) = o;
-        }
-        return;
-    }
-
-    for (int c = tid; c < BM2 * (BN / 8); c += NT) {
-        const int row = c / (BN / 8), cc = c % (BN / 8);
-        const int m = tile_row_to_m<AMODE, BM2>(a, tm, row), n = n0 + cc * 8;
-        if (m >= a.M || n >= a.N) continue;
-        const bf16x8 tv = *(const bf16x8*)(smem + row * G::EPI_LD + cc * 16);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(tv[e]);
-        long long dst;
-        if (EPI == SVR2_EPI_GATE_RES) {
-            const bf16x8 rv = *(const bf16x8*)(a.resid + (long long)m * a.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + (a.gate ? a.gate[n + e] : 1.f) * v[e];
-            dst = (long long)m * a.ldc + n;
-        } else if (EPI == SVR2_EPI_PIXSHUF3D) {
-            const int Cc = a.ps_c, tz = a.ps_tz;
-            const int qd = n / Cc, ch = n - qd * Cc;
-            const int z = qd % tz, yy = (qd / tz) & 1, xx = qd / (2 * tz);
-            const int w = m % a.ps_w, t2 = m / a.ps_w;
-            const int h = t2 % a.ps_h, f = t2 / a.ps_h;
-            int fo = f * tz + z;
-            if (a.ps_drop) {
-                if (fo == 1) continue;
-                if (fo > 1) fo -= 1;
-            }
-            dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
-        } else if (EPI == SVR2_EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = v[e], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-                v[e] = x / (1.f + __expf(-2.f * u));
-            }
-            dst = (long long)m * a.ldc + n;
-        } else {
-            if (a.resid) {
-                const bf16x8 rv = *(const bf16x8*)(a.resid + (long long)m * a.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
-            }
-            dst = (long long)m * a.ldc + n;
-        }
-        if (n + 8 <= a.N) {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-            *(bf16x8*)(a.C + dst) = o;
-        } else {
-            for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = f2bf(v[e]);
-        }
-    }
+    tile_epilogue<AMODE, EPI, BM2, BN, NT, G::EPI_LD>(a, smem, tm, n0, tid);
 }
 
 template <int AMODE, int EPI, int BN>

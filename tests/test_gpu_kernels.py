@@ -35,6 +35,36 @@ def test_gemm_bias(pkg, gpu, M, N, K):
     assert_close(out, a @ w.T + b, f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 384), (777, 2560, 2560), (256, 256, 6912), (513, 768, 192)])
+def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, monkeypatch):
+    """gemm4.hip (ping-pong 256x256x64 kernel, five LDS sub-stages): forced onto small shapes with SVR2_GEMM_V=3."""
+    monkeypatch.setenv("SVR2_GEMM_V", "3")
+    hip = pkg.hip
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, bias=b.to(gpu))
+    assert_close(out, a @ w.T + b, f"gemm4 {M}x{N}x{K}")
+
+
+def test_gemm4_pingpong_epilogues(pkg, gpu, monkeypatch):
+    monkeypatch.setenv("SVR2_GEMM_V", "3")
+    hip = pkg.hip
+    M, N, K, S = 700, 256, 256, 900
+    a, w = rnd(S, K, seed=4), rnd(N, K, seed=5, scale=1 / 16)
+    bias, gate, res = rnd(N, seed=6), rnd(N, seed=7), rnd(M, N, seed=8)
+    rows = torch.randperm(S, generator=torch.Generator().manual_seed(9))[:M].to(torch.int32)
+    out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, epilogue=hip.EPI_GATE_RES, bias=bias.to(gpu),
+                   gate=gate.to(gpu), resid=dev_bf16(res, gpu), a_rows=rows.to(gpu), m=M)
+    assert_close(out, res + gate * (a[rows.long()] @ w.T + bias), "gemm4 gather+gate+res")
+    Hd = 256
+    wg, wi = rnd(Hd, K, seed=11, scale=0.1), rnd(Hd, K, seed=12, scale=0.1)
+    out = hip.gemm(dev_bf16(a[:M], gpu), hip.pad_weight(hip.interleave_swiglu(wg, wi).to(gpu)), 2 * Hd,
+                   epilogue=hip.EPI_SWIGLU)
+    assert_close(out, F.silu(a[:M] @ wg.T) * (a[:M] @ wi.T), "gemm4 swiglu")
+    b2 = rnd(N, seed=13)
+    out = hip.gemm(dev_bf16(a[:M], gpu), hip.pad_weight(w.to(gpu)), N, epilogue=hip.EPI_GELU, bias=b2.to(gpu))
+    assert_close(out, F.gelu(a[:M] @ w.T + b2, approximate="tanh"), "gemm4 gelu")
+
+
 def test_gemm_gather_gate_res(pkg, gpu):
     hip = pkg.hip
     M, N, K, S = 700, 256, 256, 900

@@ -37,7 +37,7 @@ def rb(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
-def bench_gemm(M, N, K, epi="bias"):
+def bench_gemm(M, N, K, epi="bias", gather=False):
     a = rb(M, K)
     w = hip.pad_weight(rb(N, K, scale=1 / math.sqrt(K)))
     out = torch.empty(M, N if epi != "swiglu" else N // 2, dtype=torch.bfloat16, device=dev)
@@ -47,7 +47,8 @@ def bench_gemm(M, N, K, epi="bias"):
         fn = lambda: hip.gemm(a, w, N, out, epilogue=hip.EPI_SWIGLU)
     else:
         res, gate = rb(M, N), torch.randn(N, device=dev)
-        fn = lambda: hip.gemm(a, w, N, out, epilogue=hip.EPI_GATE_RES, gate=gate, resid=res)
+        rows = torch.randperm(M, device=dev).to(torch.int32) if gather else None
+        fn = lambda: hip.gemm(a, w, N, out, epilogue=hip.EPI_GATE_RES, gate=gate, resid=res, a_rows=rows, m=M)
     t = timeit(fn)
     print(f"gemm[{epi}] M={M} N={N} K={K}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s", flush=True)
 
@@ -137,6 +138,13 @@ if __name__ == "__main__":
         bench_gn(4, 2160, 3840, 128)
         bench_gn(4, 1080, 1920, 256)
         bench_gn(4, 2160, 3840, 256)
+    if "gemmdit" in which:   # the four GEMMs of a NaDiT-3B layer at the 4K batch size, proj_out with its row gather
+        print("SVR2_GEMM4 =", os.environ.get("SVR2_GEMM4", "1"))
+        M = 194400
+        bench_gemm(M, 7680, 2560)
+        bench_gemm(M, 2560, 2560, "gate", gather=True)
+        bench_gemm(M, 13824, 2560, "swiglu")
+        bench_gemm(M, 2560, 6912, "gate")
     if "gemmsmall" in which:   # the memory-bound / narrow GEMMs of the VAE (run once per SVR2_GEMM_V value)
         print("SVR2_GEMM_V =", os.environ.get("SVR2_GEMM_V", "2"))
         bench_gemm(33177600, 128, 128)        # encoder conv_in after im2col, 4 frames at 4K
