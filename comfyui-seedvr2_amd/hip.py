@@ -78,6 +78,7 @@ EXPORTS = [
     "svr2_wavelet_level", "svr2_wavelet_merge", "svr2_adain_ws_bytes", "svr2_adain", "svr2_rgb_to_lab",
     "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
     "svr2_rgb_to_hsv", "svr2_hue_sat_match_ws_bytes", "svr2_hue_sat_match", "svr2_hsv_to_rgb", "svr2_sat_blend",
+    "svr2_u8_to_frames", "svr2_frames_to_u8", "svr2_frames_to_yuv", "svr2_yuv_to_frames",
 ]
 
 
@@ -528,6 +529,54 @@ def crop_to_unit(x: torch.Tensor, h: int, w: int, to_unit: bool, out: Optional[t
     _check(lib().svr2_crop_to_unit(_p(x), _p(out), C.c_int32(x.shape[0]), C.c_int32(x.shape[1]), C.c_int32(x.shape[2]),
                                    C.c_int32(h), C.c_int32(w), C.c_int32(1 if to_unit else 0), _stream()),
            "svr2_crop_to_unit")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- frame I/O (next-3)
+PIX_SWAP_RB, PIX_BOTTOM_UP = 1, 2
+
+
+def _u8c(t: torch.Tensor, name: str, nbytes: int):
+    if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.numel() < nbytes:
+        raise HipError(f"{name}: expected a contiguous uint8 device tensor of at least {nbytes} bytes")
+
+
+def u8_to_frames(raw: torch.Tensor, out: torch.Tensor, row_stride: int, frame_stride: int, flags: int = 0) -> torch.Tensor:
+    """raw uint8 (packed rows) -> out bf16 [T,H,W,3] in [0,1] = bf16(fp16(u8 / 255))."""
+    _frames3(out, "u8_to_frames.out")
+    T, H, W, _ = out.shape
+    _u8c(raw, "u8_to_frames.raw", T * frame_stride)
+    _check(lib().svr2_u8_to_frames(_p(raw), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int64(row_stride),
+                                   C.c_int64(frame_stride), C.c_int32(flags), _stream()), "svr2_u8_to_frames")
+    return out
+
+
+def frames_to_u8(frames: torch.Tensor, out: torch.Tensor, row_stride: int, frame_stride: int, flags: int = 0) -> torch.Tensor:
+    """frames bf16 [T,H,W,3] in [0,1] -> packed uint8 rows, trunc(x * 255)."""
+    _frames3(frames, "frames_to_u8.frames")
+    T, H, W, _ = frames.shape
+    _u8c(out, "frames_to_u8.out", T * frame_stride)
+    _check(lib().svr2_frames_to_u8(_p(frames), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int64(row_stride),
+                                   C.c_int64(frame_stride), C.c_int32(flags), _stream()), "svr2_frames_to_u8")
+    return out
+
+
+def frames_to_yuv(frames: torch.Tensor, out: torch.Tensor, sub: int, frame_stride: int) -> torch.Tensor:
+    """frames bf16 [T,H,W,3] in [0,1] -> planar 8-bit BT.601 studio-range Y, U, V (sub = 1: 4:4:4, 2: 4:2:0)."""
+    _frames3(frames, "frames_to_yuv.frames")
+    T, H, W, _ = frames.shape
+    _u8c(out, "frames_to_yuv.out", T * frame_stride)
+    _check(lib().svr2_frames_to_yuv(_p(frames), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(sub),
+                                    C.c_int64(frame_stride), _stream()), "svr2_frames_to_yuv")
+    return out
+
+
+def yuv_to_frames(raw: torch.Tensor, out: torch.Tensor, sub: int, frame_stride: int) -> torch.Tensor:
+    _frames3(out, "yuv_to_frames.out")
+    T, H, W, _ = out.shape
+    _u8c(raw, "yuv_to_frames.raw", T * frame_stride)
+    _check(lib().svr2_yuv_to_frames(_p(raw), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(sub),
+                                    C.c_int64(frame_stride), _stream()), "svr2_yuv_to_frames")
     return out
 
 

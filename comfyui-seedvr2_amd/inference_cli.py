@@ -2,8 +2,11 @@
 """Standalone CLI with the reference's flags [ref: inference_cli.py:1216-1401] on the MI355X path.
 
 Offload / BlockSwap / tiling / torch.compile flags are accepted for drop-in compatibility and validated
-(they must stay at their "off" values: everything is resident in 288 GB of HBM).  Frame I/O: .png/.jpg via
-PIL and .pt/.npy tensors ([N,H,W,3] in [0,1]); video containers need cv2, which this image lacks.
+(they must stay at their "off" values: everything is resident in 288 GB of HBM).  Frame I/O streams through
+video_io.py: .y4m, uncompressed/MJPEG .avi, image files, .npy/.pt tensors natively, other video
+containers through cv2 or an ffmpeg binary when present; the output container follows the extension of --output
+(--output_format mp4|png|y4m|avi|npy names it when --output has none).  --chunk_size streams the clip in chunks with
+--temporal_overlap raw context frames, like the reference.
 Multi-GPU: ``--cuda_device 0,1,...`` runs one process per GPU (torch.distributed / RCCL) with the
 reference's segment split and boundary blend (parallel.py)."""
 
@@ -22,7 +25,7 @@ def parse_arguments(argv=None):
     p = argparse.ArgumentParser(description="SeedVR2 video upscaler (MI355X-native hot path)")
     p.add_argument("input", type=str)
     p.add_argument("--output", type=str, default=None)
-    p.add_argument("--output_format", type=str, default=None, choices=["mp4", "png", None])
+    p.add_argument("--output_format", type=str, default=None, choices=["mp4", "png", "y4m", "avi", "npy", None])
     p.add_argument("--model_dir", type=str, default=None)
     p.add_argument("--dit_model", type=str, default="seedvr2_ema_3b_fp16.safetensors")
     p.add_argument("--resolution", type=int, default=1080)
@@ -75,31 +78,116 @@ def parse_arguments(argv=None):
     return a
 
 
-def load_frames(path: str) -> torch.Tensor:
-    """-> [N,H,W,3] float32 in [0,1] (uint8 / 255 like the reference, inference_cli.py:231-250,543)."""
+def get_input_type(path: str, vio) -> str:
+    """'video' | 'image' | 'directory' | 'unknown' [ref: inference_cli.py:281-306]; tensor files count as video."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"Input path not found: {path}")
+    if os.path.isdir(path):
+        return "directory"
     ext = os.path.splitext(path)[1].lower()
-    if ext in (".png", ".jpg", ".jpeg", ".bmp", ".webp"):
-        from PIL import Image
-        return torch.from_numpy(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8).copy()).float().div(255)[None]
-    if ext == ".npy":
-        return torch.from_numpy(np.load(path, allow_pickle=False)).float()
-    if ext == ".pt":
-        return torch.load(path, weights_only=True).float()
-    raise SystemExit(f"unsupported input {ext!r}: video containers need cv2, which this image does not have")
+    if ext in vio.VIDEO_EXTENSIONS or ext in vio.TENSOR_EXTENSIONS:
+        return "video"
+    return "image" if ext in vio.IMAGE_EXTENSIONS else "unknown"
 
 
-def save_frames(frames: torch.Tensor, path: str):
-    arr = (frames.clamp(0, 1) * 255.0).to(torch.uint8).cpu().numpy()  # truncation like the reference (:520)
-    if path.endswith(".npy"):
-        np.save(path, arr)
-    elif arr.shape[0] == 1:
-        from PIL import Image
-        Image.fromarray(arr[0]).save(path)
+def generate_output_path(input_path: str, output_format: str, output_dir=None, input_type=None, from_directory=False) -> str:
+    """[ref: inference_cli.py:309-353]: `<stem>_upscaled.<fmt>` next to the input, `<dir>_upscaled/<stem>.<fmt>` in batch
+    mode, `<output_dir>/<stem>.<fmt>` when a directory is given; png sequences are directories."""
+    stem = os.path.splitext(os.path.basename(input_path))[0]
+    parent = os.path.dirname(os.path.abspath(input_path))
+    if output_dir:
+        base, suffix = output_dir, ""
+    elif from_directory:
+        base, suffix = os.path.join(os.path.dirname(parent), os.path.basename(parent) + "_upscaled"), ""
     else:
-        os.makedirs(path, exist_ok=True)
-        from PIL import Image
-        for i, f in enumerate(arr):
-            Image.fromarray(f).save(os.path.join(path, f"{i:06d}.png"))
+        base, suffix = parent, "_upscaled"
+    if output_format == "png":
+        name = f"{stem}{suffix}.png" if input_type == "image" else f"{stem}{suffix}"
+    else:
+        name = f"{stem}{suffix}.{output_format}"
+    return os.path.abspath(os.path.join(base, name))
+
+
+class _CollectSink:
+    """Stand-in for DeviceSink that keeps the finished frames on the device (multi-rank: exchanged before writing)."""
+
+    def __init__(self):
+        self.parts, self.frames_written = [], 0
+
+    def write(self, frames):
+        self.parts.append(frames)
+        self.frames_written += frames.shape[0]
+
+    def close(self):
+        pass
+
+
+def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, text_pos, output_path=None,
+                        dist=None, rank: int = 0, world: int = 1) -> int:
+    """One video / image / tensor file -> upscaled output; returns frames written [ref: inference_cli.py:356-523].
+    Frames stay on the device between the reader and the writer (video_io.py)."""
+    vio = pkg.video_io
+    itype = get_input_type(input_path, vio)
+    if itype == "unknown":
+        print(f"Skipping unsupported file: {input_path}", file=sys.stderr)
+        return 0
+    fmt = a.output_format or ("mp4" if itype == "video" else "png")
+    if output_path is None:
+        output_path = generate_output_path(input_path, fmt, input_type=itype)
+    elif not os.path.splitext(output_path)[1] or (fmt == "png" and itype != "image"):
+        output_path = generate_output_path(input_path, fmt, output_dir=output_path, input_type=itype)
+    reader = vio.open_reader(input_path)
+    if getattr(reader, "has_alpha", False):
+        raise NotImplementedError("RGBA alpha upscaling is out of scope (SURVEY 8f next-4)")
+    total = reader.total_frames
+    todo = total - a.skip_first_frames if itype == "video" else total
+    if itype == "video" and a.load_cap > 0:
+        todo = min(todo, a.load_cap)
+    if todo <= 0:
+        print(f"No frames to process after skipping {a.skip_first_frames} of {total}", file=sys.stderr)
+        reader.close()
+        return 0
+    first = a.skip_first_frames if itype == "video" else 0
+    base_name = os.path.splitext(os.path.basename(input_path))[0]
+
+    def run(frames, prepend):
+        return pkg.nodes.SeedVR2VideoUpscaler.run_device(
+            frames, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
+            a.temporal_overlap, prepend, a.color_correction, text_pos=text_pos)
+
+    def sink_for(w, h):
+        return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image"), dev)
+
+    log = (lambda m: print(m, flush=True)) if rank == 0 else None
+    if world == 1:
+        reader.seek(first)
+        src = vio.DeviceSource(reader, dev)
+        try:
+            n = vio.stream_upscale(src, sink_for, run, todo, a.chunk_size, a.temporal_overlap, a.prepend_frames, log)
+        finally:
+            src.close()
+        print(f"Output saved to: {output_path}")
+        return n
+    # multi-GPU: every rank streams its own segment [ref: inference_cli.py:452-471, 1048-1209], boundaries are cross-faded
+    # through the neighbour exchange, rank 0 writes
+    s, e = pkg.parallel.segment_ranges(todo, world, a.temporal_overlap, a.batch_size, True)[rank]
+    reader.seek(first + s)
+    src, coll = vio.DeviceSource(reader, dev), _CollectSink()
+    try:
+        vio.stream_upscale(src, lambda w, h: coll, run, e - s, a.chunk_size, a.temporal_overlap,
+                           a.prepend_frames if rank == 0 else 0, None)
+    finally:
+        src.close()
+    mine = torch.cat(coll.parts, dim=0) if coll.parts else torch.empty(0, 1, 1, 3, dtype=torch.bfloat16, device=dev)
+    owned = pkg.parallel.exchange_and_blend(mine, a.temporal_overlap, rank, world, dist)
+    full = pkg.parallel.gather_frames(owned, rank, world, 0, dist)
+    if rank != 0:
+        return 0
+    sink = sink_for(full.shape[2], full.shape[1])
+    sink.write(full)
+    sink.close()
+    print(f"Output saved to: {output_path}")
+    return full.shape[0]
 
 
 def main(argv=None) -> int:
@@ -108,13 +196,10 @@ def main(argv=None) -> int:
     sys.path.insert(0, os.path.dirname(here))
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    vio = pkg.video_io
     t0 = time.time()
+    dist = None
     try:
-        frames = load_frames(a.input)
-        if a.skip_first_frames:
-            frames = frames[a.skip_first_frames:]
-        if a.load_cap:
-            frames = frames[:a.load_cap]
         devs = [d for d in (a.cuda_device or "0").split(",") if d != ""]
         world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
         if len(devs) > 1 and world == 1:
@@ -122,7 +207,6 @@ def main(argv=None) -> int:
                              f"{len(devs)} --master-addr 127.0.0.1 inference_cli.py ...` (frame segments + one RCCL "
                              "neighbour exchange, parallel.py / INTEGRATION.md)")
         dev = f"cuda:{devs[local % len(devs)] if world > 1 else devs[0]}"
-        dist = None
         if world > 1:   # the reference's multi-GPU mode: one segment per rank [ref: inference_cli.py:1048-1209]
             import torch.distributed as dist
             torch.cuda.set_device(torch.device(dev))
@@ -131,30 +215,33 @@ def main(argv=None) -> int:
         vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(device=dev)
         txt = pkg.weights.find_model_file("pos_emb.pt", a.model_dir) or os.path.join(here, "pos_emb.pt")
         text_pos = torch.load(txt, weights_only=True)
-
-        def run(seg, prepend):
-            return pkg.nodes.SeedVR2VideoUpscaler.execute(
-                seg, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
-                a.temporal_overlap, prepend, a.color_correction, a.input_noise_scale, a.latent_noise_scale,
-                text_pos=text_pos)[0]
-
-        if world > 1:   # rank 0 alone applies prepend_frames [ref: inference_cli.py:981-984]
-            out = pkg.parallel.upscale_distributed(
-                lambda seg: run(seg, a.prepend_frames if rank == 0 else 0).to(dev), frames, a.temporal_overlap, rank,
-                world, dist, a.batch_size)
+        itype = get_input_type(a.input, vio)
+        nframes = 0
+        if itype == "directory":   # batch mode: every media file on its own [ref: inference_cli.py:1525-1575]
+            files = vio.list_media_files(a.input)
+            if not files:
+                raise SystemExit(f"No video or image files found in directory: {a.input}")
+            for i, fp in enumerate(files, 1):
+                if rank == 0:
+                    print(f"Processing file {i}/{len(files)}: {os.path.basename(fp)}", flush=True)
+                ftype = get_input_type(fp, vio)
+                fmt = a.output_format or ("mp4" if ftype == "video" else "png")
+                outp = generate_output_path(fp, fmt, a.output, input_type=ftype, from_directory=True)
+                keep, a.output_format = a.output_format, fmt
+                nframes += process_single_file(fp, a, pkg, dev, dit_cfg, vae_cfg, text_pos, outp, dist, rank, world)
+                a.output_format = keep
+        elif itype in ("video", "image"):
+            nframes = process_single_file(a.input, a, pkg, dev, dit_cfg, vae_cfg, text_pos, a.output, dist, rank, world)
+        else:
+            raise SystemExit(f"Unsupported input type: {a.input}")
+        if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-            if rank != 0:
-                return 0
-            out = out.cpu()
-        else:
-            out = run(frames, a.prepend_frames)
-        outp = a.output or (os.path.splitext(a.input)[0] + "_upscaled" + (".png" if out.shape[0] == 1 else ""))
-        save_frames(out, outp)
         dt = time.time() - t0
-        print(f"Average FPS: {out.shape[0] / dt:.2f} frames/sec ({out.shape[0]} frames in {dt:.2f}s)")
+        if rank == 0 and nframes:
+            print(f"Average FPS: {nframes / dt:.2f} frames/sec ({nframes} frames in {dt:.2f}s)")
         return 0
-    except Exception as e:  # exit code 1 on error [ref: inference_cli.py:1625-1629]
+    except (Exception, SystemExit) as e:  # exit code 1 on error [ref: inference_cli.py:1625-1629]
         print(f"Error: {e}", file=sys.stderr)
         return 1
 

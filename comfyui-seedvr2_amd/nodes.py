@@ -103,16 +103,38 @@ class SeedVR2VideoUpscaler(_Base):
             raise NotImplementedError("noise injection scales other than 0 are not implemented")
         if batch_size % 4 != 1:
             raise ValueError("batch_size must follow 4n+1")
+        out = cls.run_device(image, dit, vae, seed, resolution, max_resolution, batch_size, uniform_batch_size,
+                             temporal_overlap, prepend_frames, color_correction, text_pos=text_pos, pipeline=pipeline)
+        return (out.float().cpu(),)
+
+    @staticmethod
+    def prepend_reversed(x: torch.Tensor, count: int) -> torch.Tensor:
+        """pad_video_temporal(prepend=True) [ref: src/core/generation_utils.py:593-652]: `count` reversed head frames
+        (frame 0 excluded); when count >= T: the last frame repeated count-T+1 times, then frames T-1..1, then the clip."""
+        t = x.shape[0]
+        if count <= 0:
+            return x
+        if count >= t:
+            rep = x[-1:].repeat(count - t + 1, 1, 1, 1)
+            rev = x[1:].flip(0) if t > 1 else x[:0]
+            return torch.cat((rep, rev, x), dim=0)
+        return torch.cat((x[1:count + 1].flip(0), x), dim=0)
+
+    @classmethod
+    def run_device(cls, image: torch.Tensor, dit: dict, vae: dict, seed: int = 42, resolution: int = 1080,
+                   max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
+                   temporal_overlap: int = 0, prepend_frames: int = 0, color_correction: str = "lab",
+                   text_pos: torch.Tensor | None = None, pipeline=None) -> torch.Tensor:
+        """The upscaler without the host round trip: image [N,H,W,3] in [0,1] (any device / float dtype; bf16 frames that
+        are already on the device are used as they are) -> bf16 [N,H',W',3] in [0,1] on the device."""
         pipe = pipeline or _build_pipeline(dit, vae, text_pos)
-        frames = image
-        if prepend_frames > 0:  # reversed head frames, removed from the output [ref: generation_utils.py:593-652]
-            n = min(prepend_frames, max(image.shape[0] - 1, 0))
-            frames = torch.cat((image[1:n + 1].flip(0), image), dim=0) if n > 0 else image
+        frames = cls.prepend_reversed(image, prepend_frames)
         out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size,
                             color_correction=color_correction)
-        if prepend_frames > 0 and frames.shape[0] != image.shape[0]:
-            out = out[frames.shape[0] - image.shape[0]:]
-        return (out.float().cpu(),)
+        # postprocess_all_batches removes them again [ref: src/core/generation_phases.py:1377-1386]
+        if prepend_frames > 0 and prepend_frames < out.shape[0]:
+            out = out[prepend_frames:]
+        return out
 
 
 class SeedVR2Extension(ComfyExtension):  # pragma: no cover

@@ -289,6 +289,33 @@ int svr2_hsv_to_rgb(const float* h, const float* s, const float* v, void* y, int
 int svr2_sat_blend(const void* content, const void* style, const float* wav, const float* hsv, void* out, int64_t n,
                    void* stream);
 
+/* ------------------------------------------------------------------ streaming frame I/O
+ * The bytes that cross PCIe are the container's 8-bit pixels; both conversions run on the device and replace the
+ * reference's host-side cv2/numpy chains.
+ * svr2_u8_to_frames: packed 8-bit rows -> bf16 [T,H,W,3] in [0,1] = bf16(fp16(fp32(u8) / 255))
+ *   [ref: inference_cli.py:527-548 (_read_frames_from_cap: BGR->RGB, /255), :627 (.to(float16));
+ *    generation_phases.py:376-384 (-> compute dtype)].  Source pixel (t, y, x) at
+ *    src + t*frame_stride + (bottom_up ? H-1-y : y)*row_stride + 3*x.
+ * svr2_frames_to_u8: bf16 [T,H,W,3] in [0,1] -> packed rows, u8 = trunc(x * 255) [ref: inference_cli.py:520, 691, 734
+ *   ((frames * 255.0).astype(np.uint8)), :661-664 (RGB->BGR)]; row padding (row_stride - 3W <= 3 bytes) is zeroed.
+ * svr2_frames_to_yuv: the same quantisation, then the 8-bit integer BT.601 studio-range matrix
+ *   Y = ((66R+129G+25B+128)>>8)+16, U = ((-38R-74G+112B+128)>>8)+128, V = ((112R-94G-18B+128)>>8)+128; planar frames
+ *   [Y: H*W][U][V] with chroma subsampling sub = 1 (4:4:4) or 2 (4:2:0, chroma of the rounded 2x2 mean of RGB).  This is
+ *   the picture a BGR24 -> yuv420p scaler hands the reference's mp4v encoder (cv2.VideoWriter, inference_cli.py:693-706);
+ *   the arithmetic of that scaler lives in a dependency absent from the reference tree: parity unpinned, defined here.
+ * svr2_yuv_to_frames: inverse matrix R = clip((298(Y-16)+409(V-128)+128)>>8) ..., chroma replicated, then the uint8
+ *   chain of svr2_u8_to_frames. */
+#define SVR2_PIX_SWAP_RB 1   /* memory order B,G,R */
+#define SVR2_PIX_BOTTOM_UP 2 /* first row in memory is the bottom image row (AVI DIB) */
+int svr2_u8_to_frames(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
+                      int64_t frame_stride, int32_t flags, void* stream);
+int svr2_frames_to_u8(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
+                      int64_t frame_stride, int32_t flags, void* stream);
+int svr2_frames_to_yuv(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int32_t sub, int64_t frame_stride,
+                       void* stream);
+int svr2_yuv_to_frames(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int32_t sub, int64_t frame_stride,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,7 +298,34 @@ def test_cli_from_checkpoint_files(pkg, gpu, tmp_path, monkeypatch):
     dit = pkg.dit.NaDiTHip(dcfg, {k: rd(v) for k, v in dsd.items()}, gpu)
     vae = pkg.vae.VideoVAEHip(vcfg, {k: rd(v) for k, v in vsd.items()}, gpu)
     pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
-    ref = pipe.generate(lr, resolution=48, batch_size=1, temporal_overlap=0, seed=7, color_correction="lab")
-    want = (ref.float().cpu().clamp(0, 1) * 255.0).to(torch.uint8)
+    from seedvr2_ref import video_io as ovio
+    u8 = (lr * 255).round().to(torch.uint8).numpy()
+    # the CLI reads 8-bit levels and converts them on the device: uint8 -> /255 -> fp16 -> bf16 (inference_cli.py:543,627)
+    ref = pipe.generate(ovio.u8_to_unit(u8), resolution=48, batch_size=1, temporal_overlap=0, seed=7, color_correction="lab")
+    want = torch.from_numpy(ovio.unit_to_u8(ref))
     assert got.shape == want.shape == (1, 48, 64, 3)
     assert torch.equal(got, want)
+
+    # SURVEY 8f next-3, streaming: an uncompressed AVI in, chunks of 3 new frames + 1 raw context frame, prepend on the
+    # first chunk only, 4:2:0 y4m out -- equal to the oracle's restatement of the reference loop around the same pipeline
+    vio = pkg.video_io
+    clip = np.random.default_rng(35).integers(0, 256, size=(7, 24, 32, 3), dtype=np.uint8)
+    w = vio.AVIWriter(str(tmp_path / "clip.avi"), 32, 24, 25.0)
+    w.write_raw(ovio.rgb_to_bgr_rows(clip, True, w.layout.row_stride))
+    w.close()
+    rc = cli.main([str(tmp_path / "clip.avi"), "--resolution", "48", "--batch_size", "5", "--seed", "7", "--chunk_size", "3",
+                   "--temporal_overlap", "1", "--prepend_frames", "1", "--skip_first_frames", "1", "--color_correction",
+                   "wavelet", "--model_dir", str(mdir), "--output", str(tmp_path / "clip_out.y4m")])
+    assert rc == 0
+
+    def core(x, prepend):
+        y = pkg.nodes.SeedVR2VideoUpscaler.run_device(x.to(gpu), {}, {}, 7, 48, 0, 5, False, 1, prepend, "wavelet", pipeline=pipe)
+        return y.cpu()
+
+    outs = torch.cat(ovio.stream_chunks(ovio.u8_to_unit(clip[1:]), 3, 1, 1, core), dim=0)
+    assert outs.shape == (6, 48, 64, 3)
+    r = vio.open_reader(str(tmp_path / "clip_out.y4m"))
+    assert (r.total_frames, r.width, r.height, r.fps) == (6, 64, 48, 25.0)
+    raw = np.empty((6, r.layout.frame_bytes), np.uint8)
+    assert r.read_into(raw, 6) == 6
+    assert np.array_equal(raw, ovio.rgb_to_yuv(ovio.unit_to_u8(outs), 2))
