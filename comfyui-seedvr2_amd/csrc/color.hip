@@ -10,7 +10,7 @@
 
 namespace {
 
-__device__ __forceinline__ float rbf(float v) { return bf2f(f2bf(v)); }   // one bf16 rounding
+__device__ __forceinline__ float rbf(float v) { return round_bf16f(v); }   // one bf16 rounding (never folded away)
 
 // ----------------------------------------------------------------------------- wavelet level
 // low = bf16(sum_{3x3} k[dy][dx] * img[clamp(y + (dy-1)*r), clamp(x + (dx-1)*r)])   (replicate padding, dilation r)

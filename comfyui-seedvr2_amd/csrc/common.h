@@ -25,6 +25,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
+// Round to bf16 precision (nearest even), result kept in fp32.  Integer arithmetic on purpose: written as
+// (float)(__bf16)v the round trip is folded away by the compiler when the value feeds an fma (seen in the ISA of
+// tile_accumulate_kernel: mul, cvt, fmac -- the second rounding was gone), which silently changes results that must
+// follow the reference's op-by-op bf16 rounding.
+__device__ __forceinline__ float round_bf16f(float v) {
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v;   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

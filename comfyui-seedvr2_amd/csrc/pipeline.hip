@@ -14,7 +14,7 @@ struct ResizeArgs {
     int T, Hin, Win, Hout, Wout, Hp, Wp, KY, KX;
 };
 
-__device__ __forceinline__ float round_bf16(float v) { return bf2f(f2bf(v)); }
+__device__ __forceinline__ float round_bf16(float v) { return round_bf16f(v); }
 
 __global__ __launch_bounds__(256) void resize_pad_norm_kernel(const ResizeArgs a) {
     const long long total = (long long)a.T * a.Hp * a.Wp;

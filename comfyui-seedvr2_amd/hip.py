@@ -79,6 +79,7 @@ EXPORTS = [
     "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
     "svr2_rgb_to_hsv", "svr2_hue_sat_match_ws_bytes", "svr2_hue_sat_match", "svr2_hsv_to_rgb", "svr2_sat_blend",
     "svr2_u8_to_frames", "svr2_frames_to_u8", "svr2_frames_to_yuv", "svr2_yuv_to_frames",
+    "svr2_tile_accumulate", "svr2_tile_normalize",
 ]
 
 
@@ -530,6 +531,36 @@ def crop_to_unit(x: torch.Tensor, h: int, w: int, to_unit: bool, out: Optional[t
                                    C.c_int32(h), C.c_int32(w), C.c_int32(1 if to_unit else 0), _stream()),
            "svr2_crop_to_unit")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- VAE tiling (next-4)
+def tile_accumulate(tile: torch.Tensor, result: torch.Tensor, count: torch.Tensor, y0: int, x0: int, eh: int, ew: int,
+                    wh: torch.Tensor, ww: torch.Tensor) -> None:
+    """result[:, y0:y0+eh, x0:x0+ew, :C] += tile[:, :eh, :ew, :C] * wh * ww (bf16 roundings of the reference), count too."""
+    for t, n in ((tile, "tile"), (result, "result"), (count, "count"), (wh, "wh"), (ww, "ww")):
+        _bf16c(t, f"tile_accumulate.{n}")
+        if not t.is_contiguous():
+            raise HipError(f"tile_accumulate.{n}: must be contiguous")
+    if tile.dim() != 4 or result.dim() != 4 or tile.shape[0] != result.shape[0]:
+        raise HipError(f"tile_accumulate: tile {tuple(tile.shape)} / result {tuple(result.shape)} must be [T,h,w,C] with equal T")
+    T, H, W, Cc = result.shape
+    if tuple(count.shape) != (H, W) or wh.numel() < eh or ww.numel() < ew:
+        raise HipError("tile_accumulate: count must be [H,W] and the weights at least eh / ew long")
+    _check(lib().svr2_tile_accumulate(_p(tile), C.c_int32(T), C.c_int32(tile.shape[1]), C.c_int32(tile.shape[2]),
+                                      C.c_int32(tile.shape[3]), _p(result), _p(count), C.c_int32(H), C.c_int32(W),
+                                      C.c_int32(Cc), C.c_int32(y0), C.c_int32(x0), C.c_int32(eh), C.c_int32(ew), _p(wh),
+                                      _p(ww), _stream()), "svr2_tile_accumulate")
+
+
+def tile_normalize(result: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+    _bf16c(result, "tile_normalize.result")
+    _bf16c(count, "tile_normalize.count")
+    T, H, W, Cc = result.shape
+    if not result.is_contiguous() or not count.is_contiguous() or tuple(count.shape) != (H, W):
+        raise HipError("tile_normalize: result [T,H,W,C] and count [H,W] must be contiguous")
+    _check(lib().svr2_tile_normalize(_p(result), _p(count), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(Cc),
+                                     _stream()), "svr2_tile_normalize")
+    return result
 
 
 # ----------------------------------------------------------------------------------------------- frame I/O (next-3)

@@ -18,14 +18,18 @@ from . import hip
 
 
 class VideoDiffusionInfer:
-    def __init__(self, config=None, debug=None, vae_tiling_enabled: bool = False, **tiling_kwargs):
+    def __init__(self, config=None, debug=None, encode_tiled: bool = False, encode_tile_size=(512, 512),
+                 encode_tile_overlap=(64, 64), decode_tiled: bool = False, decode_tile_size=(512, 512),
+                 decode_tile_overlap=(64, 64), tile_debug: str = "false"):
+        """Same constructor arguments as the reference runner [ref: src/core/infer.py:37-52]."""
         self.config = config
         self.debug = debug
         self.vae = None   # VideoVAEHip
         self.dit = None   # NaDiTHip
-        if vae_tiling_enabled or tiling_kwargs.get("encode_tiled") or tiling_kwargs.get("decode_tiled"):
-            # 288 GB HBM: untiled by design; the approximate cosine-ramp tiling is out of scope
-            raise NotImplementedError("VAE spatial tiling is not implemented on the MI355X path (untiled fits in HBM)")
+        self.encode_tiled, self.encode_tile_size, self.encode_tile_overlap = encode_tiled, encode_tile_size, encode_tile_overlap
+        self.decode_tiled, self.decode_tile_size, self.decode_tile_overlap = decode_tiled, decode_tile_size, decode_tile_overlap
+        if str(tile_debug).lower() != "false":
+            raise NotImplementedError("tile_debug overlays are a debugging aid of the reference UI, not built here")
         self.schedule_T = 1000.0
         self.steps = 1
 
@@ -48,14 +52,16 @@ class VideoDiffusionInfer:
         out = []
         for s in samples:  # c t h w in [-1, 1]
             x = s.permute(1, 2, 3, 0).to(self.vae.device).to(torch.bfloat16).contiguous()
-            out.append(self.vae.encode(x))
+            out.append(self.vae.encode(x, tiled=self.encode_tiled, tile_size=tuple(self.encode_tile_size),
+                                       tile_overlap=tuple(self.encode_tile_overlap)))
         return out
 
     @torch.no_grad()
     def vae_decode(self, latents: List[torch.Tensor]) -> List[torch.Tensor]:
         out = []
         for z in latents:  # t h w c
-            y = self.vae.decode(z.to(self.vae.device).to(torch.bfloat16).contiguous())
+            y = self.vae.decode(z.to(self.vae.device).to(torch.bfloat16).contiguous(), tiled=self.decode_tiled,
+                                tile_size=tuple(self.decode_tile_size), tile_overlap=tuple(self.decode_tile_overlap))
             out.append(y.permute(3, 0, 1, 2))  # c t h w (view)
         return out
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Standalone CLI with the reference's flags [ref: inference_cli.py:1216-1401] on the MI355X path.
 
-Offload / BlockSwap / tiling / torch.compile flags are accepted for drop-in compatibility and validated
-(they must stay at their "off" values: everything is resident in 288 GB of HBM).  Frame I/O streams through
+Offload / BlockSwap / torch.compile flags are accepted for drop-in compatibility and validated (they must stay at
+their "off" values: everything is resident in 288 GB of HBM); the --vae_*_tiled flags run the reference's spatial tiling
+(never needed for memory here, kept for output parity with tiled reference runs).  Frame I/O streams through
 video_io.py: .y4m, uncompressed/MJPEG .avi, image files, .npy/.pt tensors natively, other video
 containers through cv2 or an ffmpeg binary when present; the output container follows the extension of --output
 (--output_format mp4|png|y4m|avi|npy names it when --output has none).  --chunk_size streams the clip in chunks with
@@ -71,8 +72,8 @@ def parse_arguments(argv=None):
     a = p.parse_args(argv)
     if a.blocks_to_swap or a.swap_io_components:
         p.error("BlockSwap is unnecessary on 288 GB HBM: leave --blocks_to_swap 0")
-    if a.vae_encode_tiled or a.vae_decode_tiled:
-        p.error("VAE tiling is not implemented on the MI355X path (untiled fits in HBM)")
+    if a.tile_debug != "false":
+        p.error("--tile_debug overlays are a debugging aid of the reference, not built here")
     if a.batch_size % 4 != 1:
         p.error("--batch_size must follow 4n+1")
     return a
@@ -212,7 +213,10 @@ def main(argv=None) -> int:
             torch.cuda.set_device(torch.device(dev))
             dist.init_process_group(backend="nccl", device_id=torch.device(dev))
         dit_cfg, = pkg.nodes.SeedVR2LoadDiTModel.execute(model=a.dit_model, device=dev)
-        vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(device=dev)
+        vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(
+            device=dev, encode_tiled=a.vae_encode_tiled, encode_tile_size=a.vae_encode_tile_size,
+            encode_tile_overlap=a.vae_encode_tile_overlap, decode_tiled=a.vae_decode_tiled,
+            decode_tile_size=a.vae_decode_tile_size, decode_tile_overlap=a.vae_decode_tile_overlap)
         txt = pkg.weights.find_model_file("pos_emb.pt", a.model_dir) or os.path.join(here, "pos_emb.pt")
         text_pos = torch.load(txt, weights_only=True)
         itype = get_input_type(a.input, vio)

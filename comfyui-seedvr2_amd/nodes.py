@@ -69,10 +69,11 @@ class SeedVR2LoadVAEModel(_Base):
                 cache_model: bool = False, encode_tiled: bool = False, encode_tile_size: int = 1024,
                 encode_tile_overlap: int = 128, decode_tiled: bool = False, decode_tile_size: int = 1024,
                 decode_tile_overlap: int = 128, tile_debug: str = "false", torch_compile_args=None, node_id=None):
-        if encode_tiled or decode_tiled:
-            raise NotImplementedError("VAE tiling is not implemented on the MI355X path (untiled fits in HBM)")
-        cfg = dict(zip(VAE_KEYS, (model, device, offload_device, cache_model, False, encode_tile_size,
-                                  encode_tile_overlap, False, decode_tile_size, decode_tile_overlap, tile_debug,
+        for what, size, ov in (("encode", encode_tile_size, encode_tile_overlap), ("decode", decode_tile_size, decode_tile_overlap)):
+            if size < 8 or ov < 0 or ov >= size:
+                raise ValueError(f"{what}_tile_size must be >= 8 and {what}_tile_overlap in [0, tile_size)")
+        cfg = dict(zip(VAE_KEYS, (model, device, offload_device, cache_model, bool(encode_tiled), encode_tile_size,
+                                  encode_tile_overlap, bool(decode_tiled), decode_tile_size, decode_tile_overlap, tile_debug,
                                   torch_compile_args, node_id)))
         return (cfg,)
 
@@ -128,6 +129,9 @@ class SeedVR2VideoUpscaler(_Base):
         """The upscaler without the host round trip: image [N,H,W,3] in [0,1] (any device / float dtype; bf16 frames that
         are already on the device are used as they are) -> bf16 [N,H',W',3] in [0,1] on the device."""
         pipe = pipeline or _build_pipeline(dit, vae, text_pos)
+        # tiling is a property of the VAE node's settings, not of the cached pipeline
+        pipe.set_tiling(**{k: vae[k] for k in ("encode_tiled", "encode_tile_size", "encode_tile_overlap", "decode_tiled",
+                                               "decode_tile_size", "decode_tile_overlap") if k in (vae or {})})
         frames = cls.prepend_reversed(image, prepend_frames)
         out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size,
                             color_correction=color_correction)

@@ -139,6 +139,16 @@ class SeedVR2Pipeline:
         self.device = torch.device(device)
         self.text_pos = text_pos.to(self.device).to(torch.bfloat16).contiguous()
         self._taps = {}
+        self.set_tiling()
+
+    def set_tiling(self, encode_tiled: bool = False, encode_tile_size: int = 1024, encode_tile_overlap: int = 128,
+                   decode_tiled: bool = False, decode_tile_size: int = 1024, decode_tile_overlap: int = 128) -> None:
+        """Spatial VAE tiling flags of the reference's VAE loader / CLI (square tiles, sizes in pixels)
+        [ref: src/core/infer.py:38-51, 160-173, 237-244; inference_cli.py:842-847]."""
+        self.encode_tiling = dict(tiled=bool(encode_tiled), tile_size=(encode_tile_size,) * 2,
+                                  tile_overlap=(encode_tile_overlap,) * 2)
+        self.decode_tiling = dict(tiled=bool(decode_tiled), tile_size=(decode_tile_size,) * 2,
+                                  tile_overlap=(decode_tile_overlap,) * 2)
 
     def _resize_taps(self, hin, win, rh, rw):
         key = (hin, win, rh, rw)
@@ -168,14 +178,14 @@ class SeedVR2Pipeline:
                       noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """lr_frames bf16 [T(4n+1),Hin,Win,3] on the device -> decoded bf16 [T,Hp,Wp,3] in ~[-1,1]."""
         x = self.transform(lr_frames, resolution, max_resolution)
-        latent = self.vae.encode(x)
+        latent = self.vae.encode(x, **self.encode_tiling)
         del x
         if noise is None:
             noise = self.make_noise(latent.shape, seed)
         noise = noise.to(self.device).contiguous()
         x0 = self.dit.one_step(noise, latent, self.text_pos)
         del latent, noise
-        return self.vae.decode(x0)
+        return self.vae.decode(x0, **self.decode_tiling)
 
     # whole clip ----------------------------------------------------------------------------
     @torch.no_grad()

@@ -233,47 +233,119 @@ class VideoVAEHip:
 
     # ------------------------------------------------------------------ public API
     @torch.no_grad()
-    def encode(self, x: torch.Tensor) -> torch.Tensor:
+    def encode(self, x: torch.Tensor, tiled: bool = False, tile_size: Tuple[int, int] = (512, 512),
+               tile_overlap: Tuple[int, int] = (64, 64)) -> torch.Tensor:
         """x bf16 [T,H,W,3] in [-1,1], T = 4n+1, H,W multiples of 8 -> latent bf16 [T_l,h,w,16]
-        (posterior mean * scaling_factor)  [ref: src/core/infer.py:117-188; attn_video_vae.py:1672-1681]."""
+        (posterior mean * scaling_factor)  [ref: src/core/infer.py:117-188; attn_video_vae.py:1672-1681].
+        tiled: spatial tiles of `tile_size` input pixels blended over `tile_overlap` [ref: attn_video_vae.py:1294-1458]."""
         cfg = self.cfg
         T = x.shape[0]
         if x.dim() != 4 or x.shape[3] != cfg.in_channels or T % 4 != 1 or x.shape[1] % 8 or x.shape[2] % 8:
             raise hip.HipError(f"encode: expected [4n+1, 8a, 8b, {cfg.in_channels}], got {tuple(x.shape)}")
-        st = _State()
-        split = cfg.encode_split
-        if split % 4 or (cfg.encode_first - 1) % 4:
+        if cfg.encode_split % 4 or (cfg.encode_first - 1) % 4:
             raise hip.HipError("encode slices must keep the x4 temporal stride aligned (first = 4a+1, split = 4b)")
+        m = self._tiled(x, self._encode_mean, tile_size, tile_overlap, 8, 1) if tiled else self._encode_mean(x)
+        return (m.float() * cfg.scaling_factor).to(torch.bfloat16).contiguous()
+
+    def _encode_mean(self, x: torch.Tensor) -> torch.Tensor:
+        """Temporal slices with carried conv state [ref: attn_video_vae.py:1246-1268] -> posterior mean [T_l,h,w,16]."""
+        cfg, T = self.cfg, x.shape[0]
+        st = _State()
         outs = []
         a = 0
         while a < T:
-            b = min(T, a + (cfg.encode_first if a == 0 else split))
+            b = min(T, a + (cfg.encode_first if a == 0 else cfg.encode_split))
             st.last = b >= T
             outs.append(self._encoder(x[a:b].contiguous(), st)[..., : cfg.latent_channels])
             st.active = True
             a = b
-        m = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
-        return (m.float() * cfg.scaling_factor).to(torch.bfloat16).contiguous()
+        return (torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]).contiguous()
 
     @torch.no_grad()
-    def decode(self, latent: torch.Tensor) -> torch.Tensor:
-        """latent bf16 [T_l,h,w,16] -> bf16 [T,H,W,3], T = 4(T_l-1)+1  [ref: src/core/infer.py:192-257]."""
+    def decode(self, latent: torch.Tensor, tiled: bool = False, tile_size: Tuple[int, int] = (512, 512),
+               tile_overlap: Tuple[int, int] = (64, 64)) -> torch.Tensor:
+        """latent bf16 [T_l,h,w,16] -> bf16 [T,H,W,3], T = 4(T_l-1)+1  [ref: src/core/infer.py:192-257].
+        tiled: spatial tiles of `tile_size` OUTPUT pixels blended over `tile_overlap` [ref: attn_video_vae.py:1460-1622]."""
         cfg = self.cfg
         if latent.dim() != 4 or latent.shape[3] != cfg.latent_channels:
             raise hip.HipError(f"decode: expected [T_l,h,w,{cfg.latent_channels}], got {tuple(latent.shape)}")
         z = (latent.float() / cfg.scaling_factor).to(torch.bfloat16).contiguous()
-        Tl = z.shape[0]
+        return self._tiled(z, self._decode_frames, tile_size, tile_overlap, 1, 8) if tiled else self._decode_frames(z)
+
+    def _decode_frames(self, z: torch.Tensor) -> torch.Tensor:
+        cfg, Tl = self.cfg, z.shape[0]
         st = _State()
-        split = cfg.decode_split
         outs = []
         a = 0
         while a < Tl:
-            b = min(Tl, a + (cfg.decode_first if a == 0 else split))
+            b = min(Tl, a + (cfg.decode_first if a == 0 else cfg.decode_split))
             st.last = b >= Tl
             outs.append(self._decoder(z[a:b].contiguous(), st))
             st.active = True
             a = b
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+    # spatial tiling -----------------------------------------------------------------------------
+    @staticmethod
+    def tile_plan(total_h: int, total_w: int, tile: Tuple[int, int], overlap: Tuple[int, int]):
+        """Latent-space tiles (y, y_end, x, x_end) in visiting order; a tile that lies inside the overlap of its
+        predecessor is skipped [ref: attn_video_vae.py:1354-1364, 1517-1527]."""
+        (th, tw), (oh, ow) = tile, overlap
+        sh, sw = max(1, th - oh), max(1, tw - ow)
+        return [(y, min(y + th, total_h), x, min(x + tw, total_w))
+                for y in range(0, total_h, sh) for x in range(0, total_w, sw)
+                if not ((y > 0 and min(y + th, total_h) - y <= oh) or (x > 0 and min(x + tw, total_w) - x <= ow))]
+
+    @staticmethod
+    def _fade(n: int, ov: int, ramp: Optional[torch.Tensor], head: bool, tail: bool) -> torch.Tensor:
+        """Ones with the raised-cosine ramp on interior edges only [ref: attn_video_vae.py:1417-1431, 1579-1593]."""
+        w = torch.ones(n, dtype=torch.bfloat16)
+        if ov > 0:
+            if head:
+                w[:ov] = ramp[:ov]
+            if tail:
+                w[-ov:] = 1 - ramp[:ov]
+        return w
+
+    def _tiled(self, x: torch.Tensor, codec, tile_size, tile_overlap, in_scale: int, out_scale: int) -> torch.Tensor:
+        """Shared body of tiled_encode (in_scale 8, out_scale 1) and tiled_decode (in_scale 1, out_scale 8): tiles are
+        planned in latent units, cut from `x` at in_scale, and their results are blended at out_scale by the HIP
+        kernels, which keep the reference's bf16 rounding after every in-place op.  The fade weights are a few hundred
+        bf16 numbers computed on the host with the reference's own torch expressions."""
+        H, W = x.shape[1], x.shape[2]
+        sf = 8
+        (tile_h, tile_w), (ov_h, ov_w) = tile_size, tile_overlap
+        lt_h, lt_w = max(1, tile_h // sf), max(1, tile_w // sf)
+        Hl, Wl = (H + in_scale - 1) // in_scale, (W + in_scale - 1) // in_scale
+        if (in_scale == sf and H <= tile_h and W <= tile_w) or (in_scale == 1 and H <= lt_h and W <= lt_w):
+            return codec(x)
+        lo_h, lo_w = max(0, min(ov_h // sf, lt_h - 1)), max(0, min(ov_w // sf, lt_w - 1))
+        # encode fades over the latent overlap, decode over `tile_overlap` output pixels (:1346-1351 vs :1510-1515)
+        rl_h, rl_w = (lo_h, lo_w) if out_scale == 1 else (ov_h, ov_w)
+
+        def ramp(steps):
+            if steps <= 0:
+                return None
+            t = torch.linspace(0, 1, steps=steps, dtype=torch.bfloat16)
+            return 0.5 - 0.5 * torch.cos(t * torch.pi)
+
+        rh, rw = ramp(rl_h), ramp(rl_w)
+        result = count = None
+        for (y, y_end, xx, x_end) in self.tile_plan(Hl, Wl, (lt_h, lt_w), (lo_h, lo_w)):
+            tile = x[:, y * in_scale:min(y_end * in_scale, H), xx * in_scale:min(x_end * in_scale, W)].contiguous()
+            out = codec(tile).contiguous()
+            if result is None:
+                result = torch.zeros(out.shape[0], Hl * out_scale, Wl * out_scale, out.shape[3], dtype=torch.bfloat16,
+                                     device=x.device)
+                count = torch.zeros(Hl * out_scale, Wl * out_scale, dtype=torch.bfloat16, device=x.device)
+            y0, x0 = y * out_scale, xx * out_scale
+            eh = min((y_end - y) * out_scale, out.shape[1], result.shape[1] - y0)
+            ew = min((x_end - xx) * out_scale, out.shape[2], result.shape[2] - x0)
+            wh = self._fade(eh, max(0, min(rl_h, eh - 1)), rh, y > 0, y_end < Hl).to(x.device)
+            ww = self._fade(ew, max(0, min(rl_w, ew - 1)), rw, xx > 0, x_end < Wl).to(x.device)
+            hip.tile_accumulate(out, result, count, y0, x0, eh, ew, wh, ww)
+            del out, tile
+        return hip.tile_normalize(result, count)
 
 
 def synthetic_state_dict(cfg: VAEConfig, device, seed: int = 0, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:

@@ -316,6 +316,18 @@ int svr2_frames_to_yuv(const void* src, void* dst, int32_t T, int32_t H, int32_t
 int svr2_yuv_to_frames(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int32_t sub, int64_t frame_stride,
                        void* stream);
 
+/* ------------------------------------------------------------------ spatial VAE tiling
+ * Blend of overlapping tile results with the roundings of the reference's in-place bf16 torch ops
+ * [ref: src/models/video_vae_v3/modules/attn_video_vae.py:1403-1452 (tiled_encode), :1565-1614 (tiled_decode)].
+ * svr2_tile_accumulate: tile bf16 [T,th,tw,Ct] (channels 0..C-1 and rows/columns 0..eh-1 / 0..ew-1 used), result bf16
+ *   [T,H,W,C], count bf16 [H,W], fade weights wh bf16 [eh], ww bf16 [ew] (device):
+ *     result[t,y0+y,x0+x,c] += bf16(bf16(tile * wh[y]) * ww[x]);   count[y0+y,x0+x] = bf16(count + wh[y]*ww[x]).
+ * svr2_tile_normalize: result = bf16(result / max(count, bf16(1e-6)))  (result.div_(count.clamp(min=1e-6))). */
+int svr2_tile_accumulate(const void* tile, int32_t T, int32_t th, int32_t tw, int32_t Ct, void* result, void* count,
+                         int32_t H, int32_t W, int32_t C, int32_t y0, int32_t x0, int32_t eh, int32_t ew, const void* wh,
+                         const void* ww, void* stream);
+int svr2_tile_normalize(void* result, const void* count, int32_t T, int32_t H, int32_t W, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

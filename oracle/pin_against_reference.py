@@ -373,6 +373,56 @@ def main():
     ct["G12.lab_of_style"] = lab
     save_file({k: v.contiguous() for k, v in ct.items()}, os.path.join(GOLD, "color_pins.safetensors"))
 
+    # ------------------------------------------------------------------ G13 spatial VAE tiling (next-4)
+    # attn_video_vae.py imports diffusers at module level, so the module cannot be imported here; its two tiling
+    # methods depend on nothing but torch, so they are taken out of the file's syntax tree and run as they are, bound to
+    # a stand-in `self` that supplies a synthetic tile codec for slicing_encode / slicing_decode.
+    import ast
+    from typing import Tuple
+    from seedvr2_ref import tiling as otile
+    vae_src = os.path.join(REF, "src/models/video_vae_v3/modules/attn_video_vae.py")
+    with open(vae_src) as fh:
+        tree = ast.parse(fh.read())
+    fns = [n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "VideoAutoencoderKL"
+           for n in c.body if isinstance(n, ast.FunctionDef) and n.name in ("tiled_encode", "tiled_decode")]
+    assert len(fns) == 2
+    ns = {"torch": torch, "Tuple": Tuple}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), vae_src, "exec"), ns)
+
+    enc_codec, dec_codec = otile.synthetic_enc_codec, otile.synthetic_dec_codec
+
+    class _FakeVAE:
+        spatial_downsample_factor = 8
+        debug = None
+        slicing_encode = staticmethod(enc_codec)
+        slicing_decode = staticmethod(dec_codec)
+
+    tt, tmeta = {}, {}
+    g = torch.Generator().manual_seed(91)
+    enc_cases = [((3, 5, 48, 64), (32, 32), (8, 8)), ((3, 5, 48, 64), (32, 40), (16, 12)), ((3, 1, 40, 72), (24, 24), (23, 9)),
+                 ((3, 5, 32, 32), (64, 64), (16, 16)), ((3, 5, 56, 48), (16, 48), (0, 24)), ((3, 5, 48, 80), (32, 32), (40, 40))]
+    dec_cases = [((4, 2, 6, 8), (32, 32), (8, 8)), ((4, 2, 6, 8), (32, 40), (13, 20)), ((4, 1, 5, 9), (24, 24), (23, 9)),
+                 ((4, 2, 4, 4), (64, 64), (16, 16)), ((4, 2, 7, 6), (16, 48), (0, 24)), ((4, 2, 6, 10), (32, 32), (40, 40))]
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for i, (shape, ts, ov) in enumerate(enc_cases):
+            x = torch.randn(*shape, generator=g).to(dt)
+            ref = ns["tiled_encode"](_FakeVAE(), x[None].clone(), tile_size=ts, tile_overlap=ov)[0]
+            mine = otile.tiled_encode(x.clone(), enc_codec, ts, ov)
+            ref = ref.reshape(mine.shape)      # single-frame inputs come back without the frame axis (:1455-1456)
+            check(f"G13 tiled_encode {tag} #{i} {shape} tile {ts} overlap {ov}", mine.float(), ref.float(), 0.0)
+            tt[f"G13.enc.{tag}.{i}.x"], tt[f"G13.enc.{tag}.{i}.out"] = x, ref
+            tmeta[f"enc.{i}"] = {"tile": ts, "overlap": ov}
+        for i, (shape, ts, ov) in enumerate(dec_cases):
+            z = torch.randn(*shape, generator=g).to(dt)
+            ref = ns["tiled_decode"](_FakeVAE(), z[None].clone(), tile_size=ts, tile_overlap=ov)[0]
+            mine = otile.tiled_decode(z.clone(), dec_codec, ts, ov)
+            ref = ref.reshape(mine.shape)
+            check(f"G13 tiled_decode {tag} #{i} {shape} tile {ts} overlap {ov}", mine.float(), ref.float(), 0.0)
+            tt[f"G13.dec.{tag}.{i}.z"], tt[f"G13.dec.{tag}.{i}.out"] = z, ref
+            tmeta[f"dec.{i}"] = {"tile": ts, "overlap": ov}
+    save_file({k: v.contiguous() for k, v in tt.items()}, os.path.join(GOLD, "tiling_pins.safetensors"),
+              metadata={"cases": json.dumps(tmeta)})
+
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
     with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:
         json.dump(meta, fh)

@@ -45,8 +45,10 @@ def test_node_inputs_and_loader_dicts(pkg, surface):
     dit_cfg, = N.SeedVR2LoadDiTModel.execute()
     vae_cfg, = N.SeedVR2LoadVAEModel.execute()
     assert list(dit_cfg) == N.DIT_KEYS and list(vae_cfg) == N.VAE_KEYS
-    with pytest.raises(NotImplementedError):
-        N.SeedVR2LoadVAEModel.execute(decode_tiled=True)
+    tiled, = N.SeedVR2LoadVAEModel.execute(decode_tiled=True, decode_tile_size=768, decode_tile_overlap=64)
+    assert (tiled["decode_tiled"], tiled["decode_tile_size"], tiled["decode_tile_overlap"], tiled["encode_tiled"]) == (True, 768, 64, False)
+    with pytest.raises(ValueError):
+        N.SeedVR2LoadVAEModel.execute(encode_tiled=True, encode_tile_size=64, encode_tile_overlap=64)
     with pytest.raises(NotImplementedError):
         N.SeedVR2VideoUpscaler.execute(torch.zeros(1, 8, 8, 3), dit_cfg, vae_cfg, color_correction="bogus", pipeline=object())
 
@@ -56,8 +58,10 @@ def test_runner_condition_matches_reference_semantics(pkg):
     lat = torch.randn(2, 3, 4, 16)
     cond = r.get_condition(torch.zeros_like(lat), lat, "sr")
     assert cond.shape == (2, 3, 4, 17) and torch.equal(cond[..., :16], lat) and (cond[..., 16] == 1).all()
+    t = pkg.infer.VideoDiffusionInfer(encode_tiled=True, encode_tile_size=(256, 256), encode_tile_overlap=(32, 32))
+    assert t.encode_tiled and not t.decode_tiled and t.decode_tile_size == (512, 512)
     with pytest.raises(NotImplementedError):
-        pkg.infer.VideoDiffusionInfer(vae_tiling_enabled=True)
+        pkg.infer.VideoDiffusionInfer(tile_debug="encode")
 
 
 def test_vae_checkpoint_key_normalisation(pkg):
