@@ -28,26 +28,27 @@ __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 
 
 __global__ __launch_bounds__(256) void u8_to_frames_kernel(const uint8_t* __restrict__ src, bf16* __restrict__ dst, int T,
                                                            int H, int W, long long row_stride, long long frame_stride,
-                                                           int swap_rb, int flip) {
+                                                           int swap_rb, int flip, int nc) {
     const long long total = (long long)T * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % W);
         const long long r = i / W;
         const int y = (int)(r % H), t = (int)(r / H);
-        const uint8_t* p = src + t * frame_stride + (long long)(flip ? H - 1 - y : y) * row_stride + x * 3;
+        const uint8_t* p = src + t * frame_stride + (long long)(flip ? H - 1 - y : y) * row_stride + x * nc;
         const int c0 = p[0], c1 = p[1], c2 = p[2];
-        dst[i * 3 + 0] = unit_from_u8(swap_rb ? c2 : c0);
-        dst[i * 3 + 1] = unit_from_u8(c1);
-        dst[i * 3 + 2] = unit_from_u8(swap_rb ? c0 : c2);
+        dst[i * nc + 0] = unit_from_u8(swap_rb ? c2 : c0);
+        dst[i * nc + 1] = unit_from_u8(c1);
+        dst[i * nc + 2] = unit_from_u8(swap_rb ? c0 : c2);
+        if (nc == 4) dst[i * 4 + 3] = unit_from_u8(p[3]);          // alpha keeps its place (RGBA / BGRA)
     }
 }
 
 __global__ __launch_bounds__(256) void frames_to_u8_kernel(const bf16* __restrict__ src, uint8_t* __restrict__ dst, int T,
                                                            int H, int W, long long row_stride, long long frame_stride,
-                                                           int swap_rb, int flip) {
+                                                           int swap_rb, int flip, int nc) {
     // one thread per pixel, plus the threads x in [W, W + pad) that zero the row padding (at most 3 bytes)
-    const int pad = (int)(row_stride - (long long)W * 3);
+    const int pad = (int)(row_stride - (long long)W * nc);
     const int WX = W + (pad > 0 ? 1 : 0);
     const long long total = (long long)T * H * WX;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -55,16 +56,17 @@ __global__ __launch_bounds__(256) void frames_to_u8_kernel(const bf16* __restric
         const int x = (int)(i % WX);
         const long long r = i / WX;
         const int y = (int)(r % H), t = (int)(r / H);
-        uint8_t* p = dst + t * frame_stride + (long long)(flip ? H - 1 - y : y) * row_stride + x * 3;
+        uint8_t* p = dst + t * frame_stride + (long long)(flip ? H - 1 - y : y) * row_stride + x * nc;
         if (x == W) {
             for (int k = 0; k < pad; ++k) p[k] = 0;
             continue;
         }
-        const bf16* s = src + (((long long)t * H + y) * W + x) * 3;
+        const bf16* s = src + (((long long)t * H + y) * W + x) * nc;
         const int c0 = u8_from_unit(s[0]), c1 = u8_from_unit(s[1]), c2 = u8_from_unit(s[2]);
         p[0] = (uint8_t)(swap_rb ? c2 : c0);
         p[1] = (uint8_t)c1;
         p[2] = (uint8_t)(swap_rb ? c0 : c2);
+        if (nc == 4) p[3] = (uint8_t)u8_from_unit(s[3]);
     }
 }
 
@@ -131,12 +133,13 @@ inline unsigned grid_for(long long n) {
 extern "C" int svr2_u8_to_frames(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
                                  int64_t frame_stride, int32_t flags, void* stream) {
     SVR2_CHECK(src && dst, SVR2_E_ARG, "svr2_u8_to_frames: null pointer");
-    SVR2_CHECK(T > 0 && H > 0 && W > 0 && row_stride >= (int64_t)W * 3 && frame_stride >= row_stride * H, SVR2_E_SHAPE,
+    const int nc = (flags & SVR2_PIX_ALPHA) ? 4 : 3;
+    SVR2_CHECK(T > 0 && H > 0 && W > 0 && row_stride >= (int64_t)W * nc && frame_stride >= row_stride * H, SVR2_E_SHAPE,
                "svr2_u8_to_frames: bad sizes (T %d H %d W %d row %lld frame %lld)", T, H, W, (long long)row_stride,
                (long long)frame_stride);
     hipLaunchKernelGGL(u8_to_frames_kernel, dim3(grid_for((long long)T * H * W)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)src, (bf16*)dst, T, H, W, (long long)row_stride, (long long)frame_stride,
-                       flags & SVR2_PIX_SWAP_RB, flags & SVR2_PIX_BOTTOM_UP);
+                       flags & SVR2_PIX_SWAP_RB, flags & SVR2_PIX_BOTTOM_UP, nc);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
@@ -144,13 +147,14 @@ extern "C" int svr2_u8_to_frames(const void* src, void* dst, int32_t T, int32_t 
 extern "C" int svr2_frames_to_u8(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
                                  int64_t frame_stride, int32_t flags, void* stream) {
     SVR2_CHECK(src && dst, SVR2_E_ARG, "svr2_frames_to_u8: null pointer");
-    SVR2_CHECK(T > 0 && H > 0 && W > 0 && row_stride >= (int64_t)W * 3 && row_stride < (int64_t)W * 3 + 4 &&
+    const int nc = (flags & SVR2_PIX_ALPHA) ? 4 : 3;
+    SVR2_CHECK(T > 0 && H > 0 && W > 0 && row_stride >= (int64_t)W * nc && row_stride < (int64_t)W * nc + 4 &&
                    frame_stride >= row_stride * H,
                SVR2_E_SHAPE, "svr2_frames_to_u8: bad sizes (T %d H %d W %d row %lld frame %lld)", T, H, W,
                (long long)row_stride, (long long)frame_stride);
     hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for((long long)T * H * (W + 1))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)src, (uint8_t*)dst, T, H, W, (long long)row_stride, (long long)frame_stride,
-                       flags & SVR2_PIX_SWAP_RB, flags & SVR2_PIX_BOTTOM_UP);
+                       flags & SVR2_PIX_SWAP_RB, flags & SVR2_PIX_BOTTOM_UP, nc);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

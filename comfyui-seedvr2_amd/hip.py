@@ -80,6 +80,8 @@ EXPORTS = [
     "svr2_rgb_to_hsv", "svr2_hue_sat_match_ws_bytes", "svr2_hue_sat_match", "svr2_hsv_to_rgb", "svr2_sat_blend",
     "svr2_u8_to_frames", "svr2_frames_to_u8", "svr2_frames_to_yuv", "svr2_yuv_to_frames",
     "svr2_tile_accumulate", "svr2_tile_normalize",
+    "svr2_alpha_stats", "svr2_alpha_guide", "svr2_alpha_sobel", "svr2_alpha_edges", "svr2_resize_plane",
+    "svr2_guided_ab", "svr2_guided_out", "svr2_alpha_refine",
 ]
 
 
@@ -563,8 +565,76 @@ def tile_normalize(result: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
     return result
 
 
+# ----------------------------------------------------------------------------------------------- RGBA alpha (next-4)
+def alpha_guide_and_edges(rgb: torch.Tensor, norm_guide: bool, norm_edges: bool, want_edges: bool = True):
+    """rgb bf16 [T,H,W,3] -> (grey guide fp32 [T,H,W], Sobel edge map fp32 [T,H,W] in [0,1] or None)
+    [ref: alpha_upscaling.py:124-189 (detect_edges_batch), :217-218]."""
+    _frames3(rgb, "alpha_guide_and_edges.rgb")
+    T, H, W, _ = rgb.shape
+    dev, st = rgb.device, _stream()
+    gray = torch.empty(T, H, W, dtype=torch.uint8, device=dev)
+    guide = torch.empty(T, H, W, dtype=torch.float32, device=dev)
+    _check(lib().svr2_alpha_guide(_p(rgb), _p(gray), _p(guide), C.c_int64(T * H * W), C.c_int32(bool(norm_guide)),
+                                  C.c_int32(bool(norm_edges)), st), "svr2_alpha_guide")
+    if not want_edges:
+        return guide, None
+    mag = torch.empty(T, H, W, dtype=torch.float64, device=dev)
+    fmax = torch.empty(T, dtype=torch.int64, device=dev)
+    _check(lib().svr2_alpha_sobel(_p(gray), _p(mag), _p(fmax), C.c_int32(T), C.c_int32(H), C.c_int32(W), st), "svr2_alpha_sobel")
+    edges = torch.empty(T, H, W, dtype=torch.float32, device=dev)
+    _check(lib().svr2_alpha_edges(_p(mag), _p(fmax), _p(edges), C.c_int32(T), C.c_int64(H * W), st), "svr2_alpha_edges")
+    return guide, edges
+
+
+def alpha_upscale(alpha: torch.Tensor, rgb: torch.Tensor, taps) -> torch.Tensor:
+    """edge_guided_alpha_upscale [ref: src/core/alpha_upscaling.py:293-430]: alpha bf16 [T,h,w] in [0,1] (the input's alpha
+    plane), rgb bf16 [T,H,W,3] (the upscaled video, [-1,1]) -> fp32 [T,H,W] in [0,1].  `taps` = the six antialiased-bicubic
+    tap tensors for (h,w) -> (H,W) (pipeline.aa_bicubic_taps, on the device).  Two data-dependent branches of the
+    reference (binary mask?, rgb.min() < 0?) are read back from the device (8 + 4 bytes)."""
+    _bf16c(alpha, "alpha_upscale.alpha")
+    _frames3(rgb, "alpha_upscale.rgb")
+    if alpha.dim() != 3 or not alpha.is_contiguous() or alpha.shape[0] != rgb.shape[0]:
+        raise HipError(f"alpha_upscale: alpha {tuple(alpha.shape)} must be contiguous [T,h,w] with T = {rgb.shape[0]} "
+                       "(the reference fails on a frame-count mismatch as well)")
+    T, h, w = alpha.shape
+    _, H, W, _ = rgb.shape
+    dev, st = rgb.device, _stream()
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    rmin = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(1024, dtype=torch.float32, device=dev)
+    _check(lib().svr2_alpha_stats(_p(alpha), C.c_int64(alpha.numel()), _p(rgb), C.c_int64(rgb.numel()), _p(counts), _p(rmin),
+                                  _p(ws), st), "svr2_alpha_stats")
+    c0, c1 = counts.tolist()
+    # binary_ratio = (near_zero + near_one) / numel in fp32, > 0.95   (:325-330)
+    ratio = (torch.tensor(float(c0), dtype=torch.float32) + torch.tensor(float(c1), dtype=torch.float32)) / alpha.numel()
+    binary = bool(ratio > 0.95)
+    mn = float(rmin.item())
+    norm_guide = mn < 0
+    mn2 = (torch.tensor(mn, dtype=torch.float32) + 1) / 2 if norm_guide else torch.tensor(mn)
+    norm_edges = bool(mn2 < 0)
+    f32 = lambda: torch.empty(T, H, W, dtype=torch.float32, device=dev)
+    guide, edges = alpha_guide_and_edges(rgb, norm_guide, norm_edges, want_edges=binary)
+    up = f32()
+    a32 = alpha.float()
+    wy, ymin, ycnt, wx, xmin, xcnt = taps
+    _check(lib().svr2_resize_plane(_p(a32), _p(up), _p(wy), _p(ymin), _p(ycnt), _p(wx), _p(xmin), _p(xcnt), C.c_int32(T),
+                                   C.c_int32(h), C.c_int32(w), C.c_int32(H), C.c_int32(W), C.c_int32(wy.shape[1]),
+                                   C.c_int32(wx.shape[1]), C.c_int32(1), st), "svr2_resize_plane")
+    r = 2 if binary else 3
+    a, b = f32(), f32()
+    _check(lib().svr2_guided_ab(_p(guide), _p(up), _p(a), _p(b), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(r),
+                                C.c_float(0.002), st), "svr2_guided_ab")
+    refined = up   # reuse
+    _check(lib().svr2_guided_out(_p(a), _p(b), _p(guide), _p(refined), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(r),
+                                 st), "svr2_guided_out")
+    out = a        # reuse
+    _check(lib().svr2_alpha_refine(_p(refined), _p(edges), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W),
+                                   C.c_int32(1 if binary else 0), st), "svr2_alpha_refine")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- frame I/O (next-3)
-PIX_SWAP_RB, PIX_BOTTOM_UP = 1, 2
+PIX_SWAP_RB, PIX_BOTTOM_UP, PIX_ALPHA = 1, 2, 4
 
 
 def _u8c(t: torch.Tensor, name: str, nbytes: int):
@@ -574,7 +644,7 @@ def _u8c(t: torch.Tensor, name: str, nbytes: int):
 
 def u8_to_frames(raw: torch.Tensor, out: torch.Tensor, row_stride: int, frame_stride: int, flags: int = 0) -> torch.Tensor:
     """raw uint8 (packed rows) -> out bf16 [T,H,W,3] in [0,1] = bf16(fp16(u8 / 255))."""
-    _frames3(out, "u8_to_frames.out")
+    _frames3(out, "u8_to_frames.out", channels=4 if flags & PIX_ALPHA else 3)
     T, H, W, _ = out.shape
     _u8c(raw, "u8_to_frames.raw", T * frame_stride)
     _check(lib().svr2_u8_to_frames(_p(raw), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int64(row_stride),
@@ -584,7 +654,7 @@ def u8_to_frames(raw: torch.Tensor, out: torch.Tensor, row_stride: int, frame_st
 
 def frames_to_u8(frames: torch.Tensor, out: torch.Tensor, row_stride: int, frame_stride: int, flags: int = 0) -> torch.Tensor:
     """frames bf16 [T,H,W,3] in [0,1] -> packed uint8 rows, trunc(x * 255)."""
-    _frames3(frames, "frames_to_u8.frames")
+    _frames3(frames, "frames_to_u8.frames", channels=4 if flags & PIX_ALPHA else 3)
     T, H, W, _ = frames.shape
     _u8c(out, "frames_to_u8.out", T * frame_stride)
     _check(lib().svr2_frames_to_u8(_p(frames), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int64(row_stride),
@@ -612,11 +682,11 @@ def yuv_to_frames(raw: torch.Tensor, out: torch.Tensor, sub: int, frame_stride: 
 
 
 # ----------------------------------------------------------------------------------------------- colour correction
-def _frames3(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+def _frames3(t: torch.Tensor, name: str, dtype=torch.bfloat16, channels: int = 3):
     if t.dtype != dtype or not t.is_cuda:
         raise HipError(f"{name}: expected a {dtype} device tensor, got {t.dtype} on {t.device}")
-    if t.dim() != 4 or t.shape[3] != 3 or not t.is_contiguous():
-        raise HipError(f"{name}: expected contiguous [F,H,W,3]")
+    if t.dim() != 4 or t.shape[3] != channels or not t.is_contiguous():
+        raise HipError(f"{name}: expected contiguous [F,H,W,{channels}]")
 
 
 def wavelet_decomposition(x: torch.Tensor, levels: int = 5, want_high: bool = True):

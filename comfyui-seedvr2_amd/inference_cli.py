@@ -138,8 +138,6 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
     elif not os.path.splitext(output_path)[1] or (fmt == "png" and itype != "image"):
         output_path = generate_output_path(input_path, fmt, output_dir=output_path, input_type=itype)
     reader = vio.open_reader(input_path)
-    if getattr(reader, "has_alpha", False):
-        raise NotImplementedError("RGBA alpha upscaling is out of scope (SURVEY 8f next-4)")
     total = reader.total_frames
     todo = total - a.skip_first_frames if itype == "video" else total
     if itype == "video" and a.load_cap > 0:
@@ -157,7 +155,8 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
             a.temporal_overlap, prepend, a.color_correction, text_pos=text_pos)
 
     def sink_for(w, h):
-        return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image"), dev)
+        return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image",
+                                              alpha=reader.layout.channels == 4), dev)
 
     log = (lambda m: print(m, flush=True)) if rank == 0 else None
     if world == 1:

@@ -95,8 +95,6 @@ class SeedVR2VideoUpscaler(_Base):
         [ref: src/interfaces/video_upscaler.py:225-571]."""
         if image.dim() != 4 or image.shape[-1] not in (3, 4):
             raise ValueError("image must be [N,H,W,3|4]")
-        if image.shape[-1] == 4:
-            raise NotImplementedError("RGBA alpha upscaling is out of scope (SURVEY 8f next-4)")
         if color_correction not in ("none",) + tuple(hip.COLOR_METHODS):
             raise NotImplementedError(f"color_correction '{color_correction}' is not implemented "
                                       f"(available: none, {', '.join(hip.COLOR_METHODS)})")

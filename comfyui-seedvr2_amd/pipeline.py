@@ -192,16 +192,24 @@ class SeedVR2Pipeline:
     def generate(self, frames: torch.Tensor, resolution: int, batch_size: int = 5, temporal_overlap: int = 0,
                  seed: int = 42, max_resolution: int = 0, uniform_batch_size: bool = False,
                  progress=None, color_correction: str = "none") -> torch.Tensor:
-        """frames [N,Hin,Win,3] float in [0,1] (any device) -> bf16 [N,true_h,true_w,3] in [0,1] on the device.
-        color_correction: 'none', 'lab', 'wavelet' or 'adain' (phase 4, against the transformed input of each batch
-        [ref: src/core/generation_phases.py:1237-1304])."""
+        """frames [N,Hin,Win,C] float in [0,1] (any device), C = 3 or 4 -> bf16 [N,true_h,true_w,C] in [0,1] on the device.
+        color_correction: 'none' or one of hip.COLOR_METHODS (phase 4, against the transformed input of each batch
+        [ref: src/core/generation_phases.py:1237-1304]).  RGBA: the colour channels take the normal path, the alpha plane
+        is upscaled with the blended RGB as edge guide before colour correction [ref: generation_phases.py:403-469,
+        1132-1190; alpha_upscaling.py] and passes through un-normalised [ref: :1325-1333]."""
         if color_correction != "none" and color_correction not in hip.COLOR_METHODS:
             raise hip.HipError(f"color_correction '{color_correction}' is not implemented "
                                f"(available: none, {', '.join(hip.COLOR_METHODS)})")
-        N, hin, win, _ = frames.shape
+        N, hin, win, C = frames.shape
+        if C not in (3, 4):
+            raise hip.HipError(f"frames must be [N,H,W,3|4], got {tuple(frames.shape)}")
         rh, rw, th, tw, ph, pw = target_dims(hin, win, resolution, max_resolution)
         batches, overlap = plan_batches(N, batch_size, temporal_overlap, uniform_batch_size)
         src = frames.to(self.device).to(torch.bfloat16)
+        alpha_src = None
+        if C == 4:
+            alpha_src = src[..., 3].contiguous()
+            src = src[..., :3].contiguous()
         # every source frame is written exactly once  [ref: generation_phases.py:868 (pre-allocated final_video)]
         final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16, device=self.device)
         w_prev = blend_weights(overlap).to(self.device) if overlap else None
@@ -224,6 +232,20 @@ class SeedVR2Pipeline:
             if progress:
                 progress(bi + 1, len(batches))
         final = final[:write]
+        alpha_out = None
+        if alpha_src is not None:
+            alpha_out = torch.empty(write, th, tw, dtype=torch.bfloat16, device=self.device)
+            taps = self._resize_taps(hin, win, th, tw)
+            for ws, we, bi, skipped in written:
+                idx = batches[bi].index
+                if len(idx) != we - ws:
+                    # the reference pairs the alpha of the PADDED batch with the frames the batch contributed and fails in
+                    # torch on the mismatch [ref: generation_phases.py:444,1157-1168; alpha_upscaling.py:82-88]
+                    raise ValueError(f"RGBA: batch {bi} holds {len(idx)} frames (4n+1 / uniform padding, overlap) but "
+                                     f"contributes {we - ws}; alpha upscaling needs equal counts (use batch sizes that "
+                                     "divide the clip into 4n+1 batches without temporal overlap, or single images)")
+                a_in = alpha_src.index_select(0, torch.tensor(idx, device=self.device)).contiguous()
+                alpha_out[ws:we] = hip.alpha_upscale(a_in, final[ws:we].contiguous(), taps).to(torch.bfloat16)
         if color_correction != "none":
             # phase 4: every batch's slice of the blended video is matched to the transformed input of the same frames
             # (re-created on demand like the reference's _reconstruct_and_transform_batch, generation_phases.py:1237-1262)
@@ -234,5 +256,6 @@ class SeedVR2Pipeline:
                 x = hip.crop_to_unit(x[: b.ori_len].contiguous(), th, tw, to_unit=False)
                 x = x[skipped:skipped + (we - ws)].contiguous()
                 final[ws:we] = hip.color_correct(final[ws:we].contiguous(), x, color_correction)
-        # phase 4 tail: clamp(-1,1)*0.5+0.5  [ref: generation_phases.py:1337]
-        return hip.crop_to_unit(final, th, tw, to_unit=True)
+        # phase 4 tail: clamp(-1,1)*0.5+0.5  [ref: generation_phases.py:1337]; alpha is attached as it is [ref: :1325-1333]
+        rgb = hip.crop_to_unit(final, th, tw, to_unit=True)
+        return rgb if alpha_out is None else torch.cat((rgb, alpha_out.unsqueeze(-1)), dim=-1)

@@ -46,8 +46,9 @@ class Layout:
 
     def __init__(self, kind: str, width: int, height: int, sub: int = 1, flags: int = 0, row_stride: int = 0):
         self.kind, self.width, self.height, self.sub, self.flags = kind, width, height, sub, flags
+        self.channels = 4 if (kind == "rgb" and flags & hip.PIX_ALPHA) else 3
         if kind == "rgb":
-            self.row_stride = row_stride or width * 3
+            self.row_stride = row_stride or width * self.channels
             self.frame_bytes = self.row_stride * height
         elif kind == "yuv":
             cw, ch = (width + sub - 1) // sub, (height + sub - 1) // sub
@@ -64,7 +65,7 @@ class Layout:
 def frames_from_bytes(raw: torch.Tensor, lay: Layout) -> torch.Tensor:
     """raw: uint8 device tensor [T, frame_bytes] in the container layout -> bf16 [T,H,W,3] in [0,1]."""
     T = raw.shape[0]
-    out = torch.empty(T, lay.height, lay.width, 3, dtype=torch.bfloat16, device=raw.device)
+    out = torch.empty(T, lay.height, lay.width, lay.channels, dtype=torch.bfloat16, device=raw.device)
     if lay.kind == "rgb":
         hip.u8_to_frames(raw, out, lay.row_stride, lay.frame_bytes, lay.flags)
     else:
@@ -75,8 +76,9 @@ def frames_from_bytes(raw: torch.Tensor, lay: Layout) -> torch.Tensor:
 def frames_to_bytes(frames: torch.Tensor, lay: Layout, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 device frames [T,H,W,3] in [0,1] -> uint8 device tensor [T, frame_bytes] in the container layout."""
     T = frames.shape[0]
-    if tuple(frames.shape[1:]) != (lay.height, lay.width, 3):
-        raise VideoIOError(f"writer expects {lay.width}x{lay.height} frames, got {tuple(frames.shape)}")
+    if tuple(frames.shape[1:]) != (lay.height, lay.width, lay.channels):
+        raise VideoIOError(f"writer expects {lay.width}x{lay.height}x{lay.channels} frames, got {tuple(frames.shape)}"
+                           + (" (this container has no alpha channel: write .png)" if frames.shape[-1] == 4 else ""))
     if out is None:
         out = torch.empty(T, lay.frame_bytes, dtype=torch.uint8, device=frames.device)
     if lay.kind == "rgb":
@@ -293,8 +295,9 @@ class ImageFilesReader(Reader):
         from PIL import Image
         self.paths, self.fps, self.total_frames = paths, fps, len(paths)
         with Image.open(paths[0]) as im:
+            # alpha is preserved like cv2.IMREAD_UNCHANGED does [ref: inference_cli.py:254-266]
             self.has_alpha = im.mode in ("RGBA", "LA") or "transparency" in im.info
-            self.layout = Layout("rgb", im.width, im.height)
+            self.layout = Layout("rgb", im.width, im.height, flags=hip.PIX_ALPHA if self.has_alpha else 0)
         self._pos = 0
 
     def seek(self, frame: int) -> None:
@@ -305,18 +308,13 @@ class ImageFilesReader(Reader):
         got = 0
         while got < n and self._pos < self.total_frames:
             with Image.open(self.paths[self._pos]) as im:
-                a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+                a = np.asarray(im.convert("RGBA" if self.has_alpha else "RGB"), dtype=np.uint8)
             if a.shape[:2] != (self.layout.height, self.layout.width):
                 raise VideoIOError(f"{self.paths[self._pos]}: size differs from the first frame")
             buf[got] = a.reshape(-1)
             got += 1
             self._pos += 1
         return got
-
-    def read_alpha(self, index: int) -> Optional[np.ndarray]:
-        from PIL import Image
-        with Image.open(self.paths[index]) as im:
-            return np.asarray(im.convert("RGBA"), dtype=np.uint8)[..., 3].copy() if self.has_alpha else None
 
 
 class Cv2Reader(Reader):  # pragma: no cover  (cv2 is not in this image)
@@ -515,8 +513,9 @@ class AVIWriter(Writer):
 class PngSequenceWriter(Writer):
     """{base}_{index:06d}.png files [ref: inference_cli.py:709-749]; PNG compression runs on a thread pool."""
 
-    def __init__(self, directory: str, base_name: str, width: int, height: int, start_index: int = 0, workers: int = 8):
-        self.layout = Layout("rgb", width, height)
+    def __init__(self, directory: str, base_name: str, width: int, height: int, start_index: int = 0, workers: int = 8,
+                 alpha: bool = False):
+        self.layout = Layout("rgb", width, height, flags=hip.PIX_ALPHA if alpha else 0)
         os.makedirs(directory, exist_ok=True)
         self.dir, self.base, self.idx = directory, base_name, start_index
         self.pool, self.pending = ThreadPoolExecutor(max_workers=workers), []
@@ -529,7 +528,7 @@ class PngSequenceWriter(Writer):
         lay = self.layout
         for fr in buf:
             path = os.path.join(self.dir, f"{self.base}_{self.idx:06d}.png")
-            self.pending.append(self.pool.submit(self._save, fr.reshape(lay.height, lay.width, 3).copy(), path))
+            self.pending.append(self.pool.submit(self._save, fr.reshape(lay.height, lay.width, lay.channels).copy(), path))
             self.idx += 1
         while len(self.pending) > 32:
             self.pending.pop(0).result()
@@ -543,13 +542,13 @@ class PngSequenceWriter(Writer):
 class ImageWriter(Writer):
     """A single image file (PIL picks the codec from the extension)."""
 
-    def __init__(self, path: str, width: int, height: int):
-        self.layout, self.path = Layout("rgb", width, height), path
+    def __init__(self, path: str, width: int, height: int, alpha: bool = False):
+        self.layout, self.path = Layout("rgb", width, height, flags=hip.PIX_ALPHA if alpha else 0), path
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
 
     def write_raw(self, buf: np.ndarray) -> None:
         from PIL import Image
-        Image.fromarray(buf[0].reshape(self.layout.height, self.layout.width, 3)).save(self.path)
+        Image.fromarray(buf[0].reshape(self.layout.height, self.layout.width, self.layout.channels)).save(self.path)
 
 
 class NpyWriter(Writer):
@@ -607,12 +606,15 @@ class FfmpegWriter(Y4MWriter):  # pragma: no cover
             raise VideoIOError("ffmpeg failed")
 
 
-def open_writer(path: str, width: int, height: int, fps: float = 30.0, base_name: str = "frame", single_image: bool = False) -> Writer:
+def open_writer(path: str, width: int, height: int, fps: float = 30.0, base_name: str = "frame", single_image: bool = False,
+                alpha: bool = False) -> Writer:
     ext = os.path.splitext(path)[1].lower()
     if single_image and ext in IMAGE_EXTENSIONS:
-        return ImageWriter(path, width, height)
+        return ImageWriter(path, width, height, alpha)
     if ext == "":
-        return PngSequenceWriter(path, base_name, width, height)
+        return PngSequenceWriter(path, base_name, width, height, alpha=alpha)
+    if alpha:
+        raise VideoIOError(f"{ext} has no alpha channel: write RGBA results as .png / a PNG directory")
     if ext == ".y4m":
         return Y4MWriter(path, width, height, fps)
     if ext == ".avi" and not _have_cv2():

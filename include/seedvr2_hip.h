@@ -307,6 +307,8 @@ int svr2_sat_blend(const void* content, const void* style, const float* wav, con
  *   chain of svr2_u8_to_frames. */
 #define SVR2_PIX_SWAP_RB 1   /* memory order B,G,R */
 #define SVR2_PIX_BOTTOM_UP 2 /* first row in memory is the bottom image row (AVI DIB) */
+#define SVR2_PIX_ALPHA 4     /* four channels per pixel on both sides (RGBA / BGRA <-> [T,H,W,4]); alpha is converted
+                                like a colour channel [ref: inference_cli.py:262-270, 656-664] */
 int svr2_u8_to_frames(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
                       int64_t frame_stride, int32_t flags, void* stream);
 int svr2_frames_to_u8(const void* src, void* dst, int32_t T, int32_t H, int32_t W, int64_t row_stride,
@@ -327,6 +329,35 @@ int svr2_tile_accumulate(const void* tile, int32_t T, int32_t th, int32_t tw, in
                          int32_t H, int32_t W, int32_t C, int32_t y0, int32_t x0, int32_t eh, int32_t ew, const void* wh,
                          const void* ww, void* stream);
 int svr2_tile_normalize(void* result, const void* count, int32_t T, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------ RGBA inputs: edge-guided alpha upscaling (next-4)
+ * [ref: src/core/alpha_upscaling.py:124-430 (detect_edges_batch, guided_filter_pytorch, edge_guided_alpha_upscale);
+ *  call site src/core/generation_phases.py:1132-1190].  Planes are fp32 [T,H,W]; rgb is the blended upscaled video,
+ * channels-last bf16 [T,H,W,3] in [-1,1] (before colour correction).  hip.alpha_upscale() chains them.
+ * svr2_alpha_stats: counts[0] = |{alpha < 0.1}|, counts[1] = |{alpha > 0.9}| (binary-mask test, :325-330) and
+ *   rgb_min[0] = min(rgb) (the two "if x.min() < 0: x = (x+1)/2" branches, :346-348 and :147-149); workspace >= 4 KiB.
+ * svr2_alpha_guide: guide = mean over channels of the (optionally normalised) rgb in fp32 (:217-218) and the uint8 grey
+ *   image of cv2.cvtColor(RGB2GRAY) on uint8(clip(x*255)): (4899 R + 9617 G + 1868 B + 8192) >> 14.
+ * svr2_alpha_sobel: mag = sqrt(sx^2 + sy^2) in float64, 3x3 Sobel with BORDER_REFLECT_101 (cv2.Sobel(CV_64F, ksize=3)),
+ *   frame_max[t] (8 bytes each) = max over the frame.  svr2_alpha_edges: uint8(mag / max * 255) / 255 (:167-177).
+ * svr2_resize_plane: F.interpolate(bicubic, antialias=True) of a fp32 plane, tap tables as svr2_resize_pad_normalize.
+ * svr2_guided_ab / svr2_guided_out: _apply_guided_filter (:233-290), box filter = avg_pool2d(2r+1, 1, r).
+ * svr2_alpha_refine: binary != 0: steps 3-8 of the binary-mask branch (:372-410); then clamp(0,1) (:427). */
+int svr2_alpha_stats(const void* alpha, int64_t n_alpha, const void* rgb, int64_t n_rgb, int32_t* counts, float* rgb_min,
+                     void* workspace, void* stream);
+int svr2_alpha_guide(const void* rgb, void* gray, float* guide, int64_t npix, int32_t norm_guide, int32_t norm_edges,
+                     void* stream);
+int svr2_alpha_sobel(const void* gray, double* mag, void* frame_max, int32_t T, int32_t H, int32_t W, void* stream);
+int svr2_alpha_edges(const double* mag, const void* frame_max, float* edges, int32_t T, int64_t HW, void* stream);
+int svr2_resize_plane(const float* in, float* out, const float* wy, const int32_t* ymin, const int32_t* ycnt,
+                      const float* wx, const int32_t* xmin, const int32_t* xcnt, int32_t T, int32_t Hin, int32_t Win,
+                      int32_t Hout, int32_t Wout, int32_t KY, int32_t KX, int32_t clamp01, void* stream);
+int svr2_guided_ab(const float* guide, const float* src, float* a, float* b, int32_t T, int32_t H, int32_t W,
+                   int32_t radius, float eps, void* stream);
+int svr2_guided_out(const float* a, const float* b, const float* guide, float* out, int32_t T, int32_t H, int32_t W,
+                    int32_t radius, void* stream);
+int svr2_alpha_refine(const float* refined, const float* edges, float* out, int32_t T, int32_t H, int32_t W,
+                      int32_t binary, void* stream);
 
 #ifdef __cplusplus
 }

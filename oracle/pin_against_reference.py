@@ -423,6 +423,42 @@ def main():
     save_file({k: v.contiguous() for k, v in tt.items()}, os.path.join(GOLD, "tiling_pins.safetensors"),
               metadata={"cases": json.dumps(tmeta)})
 
+    # ------------------------------------------------------------------ G14 edge-guided alpha upscaling (next-4)
+    # alpha_upscaling.py needs cv2 for two calls (RGB2GRAY on uint8, 3x3 Sobel in float64); the stand-in below serves
+    # them from the oracle's restatement of OpenCV's documented arithmetic (unpinned), everything else is the reference.
+    from seedvr2_ref import alpha as oalpha
+    mod_cv2 = types.ModuleType("cv2")
+    mod_cv2.COLOR_RGB2GRAY, mod_cv2.CV_64F = 7, 6
+    mod_cv2.cvtColor = lambda frame, code: oalpha.rgb_to_gray_u8(frame)
+    mod_cv2.Sobel = lambda gray, ddepth, dx, dy, ksize=3: oalpha.sobel_f64(gray, dx, dy)
+    sys.modules["cv2"] = mod_cv2
+    au = importlib.import_module("src.core.alpha_upscaling")
+    at = {}
+    g = torch.Generator().manual_seed(93)
+    yy, xx = torch.meshgrid(torch.arange(12.0), torch.arange(16.0), indexing="ij")
+    blob = ((yy - 5.5) ** 2 / 14 + (xx - 8) ** 2 / 30 < 1).float()
+    a_bin = torch.stack([blob, blob.roll(2, 1)])[:, None]                                   # binary mask
+    a_grad = torch.stack([(xx / 15), ((yy / 11) * (xx / 15)).sqrt()])[:, None].contiguous()  # gradient alpha
+    small = torch.rand(2, 3, 12, 16, generator=g)
+    for tag, a_in in (("binary", a_bin), ("gradient", a_grad), ("matte", a_bin)):
+        # the upscaled RGB shows the matte's edge (like a real cut-out) plus texture, in [-1, 1]; "matte" is a clean
+        # cut-out (flat foreground on a faint gradient): edges only along the matte, so the snapping rules dominate
+        if tag == "matte":
+            up = torch.nn.functional.interpolate(a_in, size=(48, 64), mode="bilinear")
+            bg = torch.linspace(0.1, 0.2, 64).view(1, 1, 1, 64).expand(2, 3, 48, 64)
+            rgb = (up * torch.tensor([0.9, 0.6, 0.3]).view(1, 3, 1, 1) + (1 - up) * bg) * 2 - 1
+        else:
+            rgb = torch.nn.functional.interpolate(small * 0.6 + a_in * 0.4, size=(48, 64), mode="bicubic").clamp(0, 1) * 2 - 1
+        rgb = rgb.to(torch.bfloat16)
+        ref = au.edge_guided_alpha_upscale(a_in.to(torch.bfloat16), torch.zeros(2, 3, 12, 16), rgb, method="guided", debug=None)
+        mine = oalpha.edge_guided_alpha_upscale(a_in.to(torch.bfloat16), rgb)
+        check(f"G14 edge_guided_alpha_upscale {tag}", mine, ref, 0.0)
+        at[f"G14.{tag}.alpha"], at[f"G14.{tag}.rgb"], at[f"G14.{tag}.out"] = a_in.to(torch.bfloat16), rgb, ref
+    edges_ref = au.detect_edges_batch(images=(at["G14.binary.rgb"].float() + 1) / 2, method="sobel", debug=None)
+    check("G14 detect_edges_batch", oalpha.detect_edges((at["G14.binary.rgb"].float() + 1) / 2), edges_ref, 0.0)
+    at["G14.binary.edges"] = edges_ref
+    save_file({k: v.contiguous() for k, v in at.items()}, os.path.join(GOLD, "alpha_pins.safetensors"))
+
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
     with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:
         json.dump(meta, fh)
