@@ -172,6 +172,9 @@ if __name__ == "__main__":
         bench_conv(5, 544, 960, 256, 256)
         bench_conv(5, 1088, 1920, 128, 128)
         bench_conv(4, 2160, 3840, 128, 128)
+    if "attn5" in which:
+        bench_attn512(1, 129600)
+        bench_attn512(2, 32640)
     if "attn" in which:
         bench_attn((3, 68, 120), pkg.windows.REGULAR)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
