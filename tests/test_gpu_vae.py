@@ -144,18 +144,24 @@ def _color_pair(T=3, H=40, W=56, seed=5):
 @pytest.mark.parametrize("method", ["wavelet", "adain", "lab", "hsv", "wavelet_adaptive"])
 def test_color_correction_vs_oracle(pkg, gpu, method):
     """Phase-4 colour correction kernels (color.hip) against the oracle (pinned on the reference's color_fix.py) on
-    bf16 frames.  Tolerance: the reference rounds to bf16 after every op, the kernels round at the same places but
-    accumulate the 3x3 stencil / moments in a different order: <= 2 bf16 ulp at |v| ~ 1 (1.6e-2) per pixel, and a mean
-    error far below one ulp; LAB adds pow() differences and the unspecified order of tied ranks (see oracle)."""
+    bf16 frames.  The reference rounds to bf16 after every op and so do the kernels (integer rounding helper, same
+    summation order): wavelet, adain and wavelet_adaptive are BIT-EXACT.  lab / hsv go through pow() / atan-free hue math
+    and rank transfers whose tied ranks and quantile indices are unspecified in the reference: >= 99.9 % / 99 % of the
+    values are identical, the rest within 1e-3 (lab) / 4e-2 (hsv: a pixel that changes hue bin takes another quantile)."""
     from seedvr2_ref import color as ocol
     c, s_ = _color_pair()
     ref = ocol.color_correct(c.clone(), s_.clone(), method).float()
     got = pkg.hip.color_correct(c.to(gpu), s_.to(gpu), method).float().cpu()
     d = (got - ref).abs()
     assert got.shape == ref.shape and torch.isfinite(got).all()
-    sorted_modes = ("lab", "hsv", "wavelet_adaptive")       # rank transfers: tied ranks / quantile indices may differ
-    assert d.max().item() <= (4e-2 if method in sorted_modes else 1.6e-2), d.max().item()
-    assert d.mean().item() <= (2e-3 if method in sorted_modes else 5e-4), d.mean().item()
+    exact = (d == 0).float().mean().item()
+    print(f"color[{method}]: max|d| {d.max().item():.3e}, identical {exact:.5f}")
+    if method in ("wavelet", "adain", "wavelet_adaptive"):
+        assert torch.equal(got, ref)
+    elif method == "lab":
+        assert d.max().item() <= 2e-3 and exact >= 0.999
+    else:
+        assert d.max().item() <= 4e-2 and exact >= 0.99 and d.mean().item() <= 1e-4
 
 
 def test_hist_match_is_a_rank_transfer(pkg, gpu):
