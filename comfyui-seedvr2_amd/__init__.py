@@ -17,6 +17,7 @@ from . import pipeline  # noqa: F401
 from . import parallel  # noqa: F401
 from . import weights  # noqa: F401
 from . import infer  # noqa: F401
+from . import jpeg  # noqa: F401
 from . import video_io  # noqa: F401
 from . import nodes  # noqa: F401
 from .nodes import comfy_entrypoint, SeedVR2Extension  # noqa: F401  (ComfyUI V3 entry point)

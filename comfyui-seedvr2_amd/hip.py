@@ -66,7 +66,8 @@ class QkvPrepDesc(C.Structure):
 
 _lib = None
 _zero_pages = {}
-_INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes", "svr2_hue_sat_match_ws_bytes")
+_INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes", "svr2_hue_sat_match_ws_bytes",
+              "svr2_jpeg_ws_bytes")
 
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -82,6 +83,7 @@ EXPORTS = [
     "svr2_tile_accumulate", "svr2_tile_normalize",
     "svr2_alpha_stats", "svr2_alpha_guide", "svr2_alpha_sobel", "svr2_alpha_edges", "svr2_resize_plane",
     "svr2_guided_ab", "svr2_guided_out", "svr2_alpha_refine",
+    "svr2_jpeg_ws_bytes", "svr2_jpeg_encode",
 ]
 
 
@@ -563,6 +565,32 @@ def tile_normalize(result: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
     _check(lib().svr2_tile_normalize(_p(result), _p(count), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(Cc),
                                      _stream()), "svr2_tile_normalize")
     return result
+
+
+# ----------------------------------------------------------------------------------------------- JPEG (next-3)
+_jpeg_tables = {}
+
+
+def jpeg_encode(frames: torch.Tensor, quality: int = 90):
+    """frames bf16 [T,H,W,3] in [0,1] -> (packed uint8 [T, cap] entropy-coded scans, lengths int32 [T]) on the device.
+    Header / EOI: jpeg.frame_header(W, H, quality) + scan + b"\xff\xd9"."""
+    from . import jpeg as _jpeg
+    _frames3(frames, "jpeg_encode.frames")
+    T, H, W, _ = frames.shape
+    dev = frames.device
+    key = (dev.index, int(quality))
+    if key not in _jpeg_tables:
+        div, huff = _jpeg.device_tables(quality)
+        _jpeg_tables[key] = (torch.from_numpy(div).to(dev), torch.from_numpy(huff.view("int32").copy()).to(dev))
+    div, huff = _jpeg_tables[key]
+    cap = H * W * 3 // 2 + 4096
+    ws_bytes = int(lib().svr2_jpeg_ws_bytes(C.c_int32(T), C.c_int32(H), C.c_int32(W)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    packed = torch.empty(T, cap, dtype=torch.uint8, device=dev)
+    lens = torch.empty(T, dtype=torch.int32, device=dev)
+    _check(lib().svr2_jpeg_encode(_p(frames), C.c_int32(T), C.c_int32(H), C.c_int32(W), _p(div), _p(huff), _p(packed),
+                                  C.c_int64(cap), _p(lens), _p(ws), C.c_int64(ws_bytes), _stream()), "svr2_jpeg_encode")
+    return packed, lens
 
 
 # ----------------------------------------------------------------------------------------------- RGBA alpha (next-4)

@@ -6,7 +6,7 @@ their "off" values: everything is resident in 288 GB of HBM); the --vae_*_tiled 
 (never needed for memory here, kept for output parity with tiled reference runs).  Frame I/O streams through
 video_io.py: .y4m, uncompressed/MJPEG .avi, image files, .npy/.pt tensors natively, other video
 containers through cv2 or an ffmpeg binary when present; the output container follows the extension of --output
-(--output_format mp4|png|y4m|avi|npy names it when --output has none).  --chunk_size streams the clip in chunks with
+(--output_format mp4|png|y4m|avi|mjpeg|npy names it when --output has none; mjpeg = Motion-JPEG AVI encoded on the device).  --chunk_size streams the clip in chunks with
 --temporal_overlap raw context frames, like the reference.
 Multi-GPU: ``--cuda_device 0,1,...`` runs one process per GPU (torch.distributed / RCCL) with the
 reference's segment split and boundary blend (parallel.py)."""
@@ -26,7 +26,7 @@ def parse_arguments(argv=None):
     p = argparse.ArgumentParser(description="SeedVR2 video upscaler (MI355X-native hot path)")
     p.add_argument("input", type=str)
     p.add_argument("--output", type=str, default=None)
-    p.add_argument("--output_format", type=str, default=None, choices=["mp4", "png", "y4m", "avi", "npy", None])
+    p.add_argument("--output_format", type=str, default=None, choices=["mp4", "png", "y4m", "avi", "mjpeg", "npy", None])
     p.add_argument("--model_dir", type=str, default=None)
     p.add_argument("--dit_model", type=str, default="seedvr2_ema_3b_fp16.safetensors")
     p.add_argument("--resolution", type=int, default=1080)
@@ -133,10 +133,12 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
         print(f"Skipping unsupported file: {input_path}", file=sys.stderr)
         return 0
     fmt = a.output_format or ("mp4" if itype == "video" else "png")
+    mjpeg = 90 if fmt == "mjpeg" else 0          # Motion-JPEG in AVI, encoded on the device (video_io.MJPEGWriter)
+    ext = "avi" if mjpeg else fmt
     if output_path is None:
-        output_path = generate_output_path(input_path, fmt, input_type=itype)
+        output_path = generate_output_path(input_path, ext, input_type=itype)
     elif not os.path.splitext(output_path)[1] or (fmt == "png" and itype != "image"):
-        output_path = generate_output_path(input_path, fmt, output_dir=output_path, input_type=itype)
+        output_path = generate_output_path(input_path, ext, output_dir=output_path, input_type=itype)
     reader = vio.open_reader(input_path)
     total = reader.total_frames
     todo = total - a.skip_first_frames if itype == "video" else total
@@ -156,7 +158,7 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
 
     def sink_for(w, h):
         return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image",
-                                              alpha=reader.layout.channels == 4), dev)
+                                              alpha=reader.layout.channels == 4, mjpeg_quality=mjpeg), dev)
 
     log = (lambda m: print(m, flush=True)) if rank == 0 else None
     if world == 1:

@@ -510,6 +510,75 @@ class AVIWriter(Writer):
         self.f.close()
 
 
+class MJPEGWriter(Writer):
+    """Motion-JPEG: AVI ('MJPG' stream, one JPEG per '00dc' chunk, idx1 index), or a directory of .jpg files.  The frames
+    are encoded ON THE DEVICE (hip.jpeg_encode -> csrc/jpeg.hip); this class only adds the constant header and EOI and
+    writes bytes.  ~10-20x smaller than raw frames, so AVI's 4 GiB limit holds thousands of 4K frames."""
+    device_encodes = True
+    LIMIT = (1 << 32) - (1 << 20)
+
+    def __init__(self, path: str, width: int, height: int, fps: float, quality: int = 90, base_name: str = "frame"):
+        from . import jpeg as _jpeg
+        self.layout = Layout("rgb", width, height)
+        self.quality, self.fps, self.n = int(quality), fps, 0
+        self.header = _jpeg.frame_header(width, height, self.quality)
+        self.avi = os.path.splitext(path)[1].lower() == ".avi"
+        self.path, self.base = path, base_name
+        self._index: List[Tuple[int, int]] = []
+        if self.avi:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            self.f = open(path, "wb")
+            self.f.write(self._headers(0, 0, 0))
+            self._movi = self.f.tell() - 4
+        else:
+            os.makedirs(path, exist_ok=True)
+
+    def device_encode(self, frames: torch.Tensor):
+        return hip.jpeg_encode(frames, self.quality)
+
+    def _headers(self, nframes: int, movi_bytes: int, max_chunk: int) -> bytes:
+        lay = self.layout
+        num, den = _fps_fraction(self.fps)
+        mjpg = struct.unpack("<I", b"MJPG")[0]
+        strf = struct.pack("<IiiHHIIiiII", 40, lay.width, lay.height, 1, 24, mjpg, lay.width * lay.height * 3, 0, 0, 0, 0)
+        strh = struct.pack("<4s4sIHHIIIIIIIIhhhh", b"vids", b"MJPG", 0, 0, 0, 0, den, num, 0, nframes, max_chunk, 0xFFFFFFFF, 0, 0,
+                           0, lay.width, lay.height)
+        strl = b"strl" + b"strh" + struct.pack("<I", len(strh)) + strh + b"strf" + struct.pack("<I", len(strf)) + strf
+        avih = struct.pack("<IIIIIIIIII4I", int(round(1e6 * den / num)), int(max_chunk * num / den), 0, 0x10, nframes, 0, 1,
+                           max_chunk, lay.width, lay.height, 0, 0, 0, 0)
+        hdrl = b"hdrl" + b"avih" + struct.pack("<I", len(avih)) + avih + b"LIST" + struct.pack("<I", len(strl)) + strl
+        riff_sz = 4 + 8 + len(hdrl) + 8 + 4 + movi_bytes + (8 + 16 * nframes if nframes else 0)
+        return (b"RIFF" + struct.pack("<I", riff_sz) + b"AVI " + b"LIST" + struct.pack("<I", len(hdrl)) + hdrl +
+                b"LIST" + struct.pack("<I", 4 + movi_bytes) + b"movi")
+
+    def write_encoded(self, packed: np.ndarray, lens: np.ndarray) -> None:
+        for row, n in zip(packed, lens):
+            if n < 0:
+                raise VideoIOError("JPEG: a frame did not fit its buffer (noise-like content at very high quality)")
+            data = self.header + row[:n].tobytes() + b"\xff\xd9"
+            if self.avi:
+                if self.f.tell() + len(data) + 8 + 16 * (self.n + 1) + 8 > self.LIMIT:
+                    raise VideoIOError("AVI 1.0 is limited to 4 GiB: write .y4m or a directory for longer clips")
+                self._index.append((self.f.tell() - self._movi, len(data)))
+                self.f.write(b"00dc" + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b""))
+            else:
+                with open(os.path.join(self.path, f"{self.base}_{self.n:06d}.jpg"), "wb") as fh:
+                    fh.write(data)
+            self.n += 1
+
+    def close(self):
+        if not self.avi:
+            return
+        movi_bytes = self.f.tell() - self._movi - 4
+        if self.n:
+            self.f.write(b"idx1" + struct.pack("<I", 16 * self.n))
+            for off, size in self._index:
+                self.f.write(struct.pack("<4sIII", b"00dc", 0x10, off, size))
+        self.f.seek(0)
+        self.f.write(self._headers(self.n, movi_bytes, max((s for _, s in self._index), default=0)))
+        self.f.close()
+
+
 class PngSequenceWriter(Writer):
     """{base}_{index:06d}.png files [ref: inference_cli.py:709-749]; PNG compression runs on a thread pool."""
 
@@ -607,8 +676,11 @@ class FfmpegWriter(Y4MWriter):  # pragma: no cover
 
 
 def open_writer(path: str, width: int, height: int, fps: float = 30.0, base_name: str = "frame", single_image: bool = False,
-                alpha: bool = False) -> Writer:
+                alpha: bool = False, mjpeg_quality: int = 0) -> Writer:
+    """mjpeg_quality > 0: .avi / directory outputs become Motion-JPEG encoded on the device (else raw BGR24 / PNG)."""
     ext = os.path.splitext(path)[1].lower()
+    if mjpeg_quality > 0 and not alpha and not single_image and ext in (".avi", ""):
+        return MJPEGWriter(path, width, height, fps, mjpeg_quality, base_name)
     if single_image and ext in IMAGE_EXTENSIONS:
         return ImageWriter(path, width, height, alpha)
     if ext == "":
@@ -698,24 +770,28 @@ class DeviceSink:
             item = self.q.get()
             if item is None:
                 return
-            host, n, ev = item
+            host, n, ev = item[:3]
             try:
                 if self.err is None:
                     if ev is not None:
                         ev.synchronize()
-                    self.writer.write_raw(host[:n].numpy())
+                    if len(item) == 5:
+                        self.writer.write_encoded(host[:n, :item[4]].numpy(), item[3])
+                    else:
+                        self.writer.write_raw(host[:n].numpy())
             except BaseException as e:  # surfaced by the next write()/close() on the caller's thread
                 self.err = e
             finally:
                 self.free.put(host)
 
-    def _host(self, n: int) -> torch.Tensor:
+    def _host(self, n: int, width: int = 0) -> torch.Tensor:
+        width = width or self.lay.frame_bytes
         while True:
             if self.allocated < self.depth and self.free.empty():
                 self.allocated += 1
-                return torch.empty(n, self.lay.frame_bytes, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+                return torch.empty(n, width, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
             b = self.free.get()
-            if b.shape[0] >= n:
+            if b.shape[0] >= n and b.shape[1] >= width:
                 return b
             self.allocated -= 1          # too small: drop it and allocate a bigger one
 
@@ -724,6 +800,19 @@ class DeviceSink:
         if self.err is not None:
             raise self.err
         if frames.shape[0] == 0:
+            return
+        if getattr(self.writer, "device_encodes", False):
+            for i in range(0, frames.shape[0], 8):       # bounded scratch: eight frames per encode
+                part = frames[i:i + 8].contiguous()
+                packed, lens = self.writer.device_encode(part)
+                lens_h = lens.cpu()                         # tiny read-back: how many bytes to fetch
+                need = max(int(lens_h.max()), 1)
+                host = self._host(part.shape[0], need)
+                host[:part.shape[0], :need].copy_(packed[:, :need], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.q.put((host, part.shape[0], ev, lens_h.numpy(), need))
+            self.frames_written += frames.shape[0]
             return
         raw = frames_to_bytes(frames.contiguous(), self.lay)
         host = self._host(frames.shape[0])

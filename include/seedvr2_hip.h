@@ -359,6 +359,17 @@ int svr2_guided_out(const float* a, const float* b, const float* guide, float* o
 int svr2_alpha_refine(const float* refined, const float* edges, float* out, int32_t T, int32_t H, int32_t W,
                       int32_t binary, void* stream);
 
+/* ------------------------------------------------------------------ baseline JPEG for Motion-JPEG output (next-3)
+ * The reference's writer is cv2's mp4v encoder [ref: inference_cli.py:666-706]; without a codec library the compressed
+ * container offered here is MJPEG, encoded on the device (arithmetic defined by oracle/seedvr2_ref/jpeg.py, ITU-T T.81).
+ * frames bf16 [T,H,W,3] in [0,1]; div int32 [2][64] = 8*Q in zig-zag order (luma, chroma); huff uint32 [2][12+256] =
+ * length<<16 | code for the DC categories then the AC run/size symbols (tables: comfyui-seedvr2_amd/jpeg.py).
+ * packed uint8 [T][frame_cap] receives each frame's entropy-coded scan (MCU rows separated by RSTn, one restart interval
+ * per MCU row; header and EOI are the caller's), frame_len int32 [T] its length or -1 if it did not fit. */
+int64_t svr2_jpeg_ws_bytes(int32_t T, int32_t H, int32_t W);
+int svr2_jpeg_encode(const void* frames, int32_t T, int32_t H, int32_t W, const int32_t* div, const uint32_t* huff,
+                     void* packed, int64_t frame_cap, int32_t* frame_len, void* workspace, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
