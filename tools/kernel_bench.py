@@ -172,6 +172,26 @@ if __name__ == "__main__":
         bench_conv(5, 544, 960, 256, 256)
         bench_conv(5, 1088, 1920, 128, 128)
         bench_conv(4, 2160, 3840, 128, 128)
+    if "io" in which:   # HBM-bound byte kernels of the frame I/O at 4K, 17 frames
+        T, H, W = 17, 2160, 3840
+        x = torch.rand(T, H, W, 3, device=dev).to(torch.bfloat16)
+        vio = pkg.video_io
+        for name, lay, byts in (("frames_to_u8 (BGR, bottom-up)", vio.Layout("rgb", W, H, flags=3), 6 + 3),
+                                ("frames_to_yuv 4:2:0", vio.Layout("yuv", W, H, sub=2), 6 + 1.5)):
+            out = torch.empty(T, lay.frame_bytes, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: vio.frames_to_bytes(x, lay, out))
+            print(f"{name}: {t*1e3:.3f} ms  {T*H*W*byts/t/1e9:.0f} GB/s ({T/t:.0f} frames/s)", flush=True)
+            raw = out
+            t = timeit(lambda: vio.frames_from_bytes(raw, lay))
+            print(f"  inverse: {t*1e3:.3f} ms  {T*H*W*byts/t/1e9:.0f} GB/s", flush=True)
+        t = timeit(lambda: hip.jpeg_encode(x[:8], 90), iters=3, warm=1)
+        print(f"jpeg_encode q90 (8 frames, noise-like worst case): {t*1e3:.1f} ms  ({8/t:.0f} frames/s)", flush=True)
+        g = torch.Generator().manual_seed(1)
+        low = 0.5 + 0.2 * torch.randn(8, 3, 135, 240, generator=g)
+        sm = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic").clamp(0, 1).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+        t = timeit(lambda: hip.jpeg_encode(sm, 90), iters=3, warm=1)
+        _, lens = hip.jpeg_encode(sm, 90)
+        print(f"jpeg_encode q90 (8 smooth frames): {t*1e3:.1f} ms  ({8/t:.0f} frames/s, {lens.float().mean().item()/1e6:.2f} MB per frame)", flush=True)
     if "attn5" in which:
         bench_attn512(1, 129600)
         bench_attn512(2, 32640)
