@@ -35,6 +35,16 @@ VAE_KEYS = ["model", "device", "offload_device", "cache_model", "encode_tiled", 
 _PIPELINES: Dict[Any, _pipeline.SeedVR2Pipeline] = {}
 
 
+def _check_interrupt(done: int = 0, total: int = 0) -> None:
+    """Polled once per batch: ComfyUI's cancel button raises from here, like the reference's check_interrupt
+    [ref: src/core/generation_utils.py:360-366, 655-658].  A no-op outside ComfyUI."""
+    try:
+        import comfy.model_management as mm  # type: ignore
+    except Exception:
+        return
+    mm.throw_exception_if_processing_interrupted()
+
+
 def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pipeline.SeedVR2Pipeline:
     key = (dit_cfg["model"], vae_cfg["model"], dit_cfg["device"])
     if key not in _PIPELINES:
@@ -132,7 +142,7 @@ class SeedVR2VideoUpscaler(_Base):
                                                "decode_tile_size", "decode_tile_overlap") if k in (vae or {})})
         frames = cls.prepend_reversed(image, prepend_frames)
         out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size,
-                            color_correction=color_correction)
+                            progress=_check_interrupt, color_correction=color_correction)
         # postprocess_all_batches removes them again [ref: src/core/generation_phases.py:1377-1386]
         if prepend_frames > 0 and prepend_frames < out.shape[0]:
             out = out[prepend_frames:]
