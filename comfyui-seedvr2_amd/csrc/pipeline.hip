@@ -89,6 +89,29 @@ inline int grid_1d(long long n) {
     return (int)g;
 }
 
+
+// Noise injection of the reference's optional knobs, with torch's rounding: bf16 tensors, python-float scalars applied in
+// fp32 and rounded to bf16 after every op (modes 0, 1), or fp32 scalar tensors that promote the whole expression to fp32
+// (mode 2).   mode 0 (input_noise_scale, generation_phases.py:409-425):  n = y*0.05;  out = x*a + (x + n)*b
+//             mode 1 (aug noise, :679):                                   out = x*a + y*b          (a = 0.1, b = 0.05)
+//             mode 2 (schedule.forward with an fp32 timestep, :686-693):  out = bf16(fp32(a*x) + fp32(b*y))
+__global__ __launch_bounds__(256) void noise_mix_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y,
+                                                        bf16* __restrict__ out, long long n, float a, float b, int mode) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float xv = bf2f(x[i]), yv = bf2f(y[i]);
+        float r;
+        if (mode == 0) {
+            const float nz = round_bf16f(__fmul_rn(yv, 0.05f));
+            r = round_bf16f(__fadd_rn(round_bf16f(__fmul_rn(xv, a)), round_bf16f(__fmul_rn(round_bf16f(__fadd_rn(xv, nz)), b))));
+        } else if (mode == 1) {
+            r = round_bf16f(__fadd_rn(round_bf16f(__fmul_rn(xv, a)), round_bf16f(__fmul_rn(yv, b))));
+        } else {
+            r = __fadd_rn(__fmul_rn(a, xv), __fmul_rn(b, yv));
+        }
+        out[i] = f2bf(r);
+    }
+}
+
 }  // namespace
 
 extern "C" int svr2_resize_pad_normalize(const void* in, void* out, const float* wy, const int32_t* ymin,
@@ -126,6 +149,16 @@ extern "C" int svr2_crop_to_unit(const void* in, void* out, int32_t T, int32_t H
     SVR2_CHECK(T > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, SVR2_E_SHAPE, "svr2_crop_to_unit: bad sizes");
     hipLaunchKernelGGL(crop_to_unit_kernel, dim3(grid_1d((long long)T * H * W * 3)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)in, (bf16*)out, T, Hp, Wp, H, W, to_unit);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_noise_mix(const void* x, const void* y, void* out, int64_t n, float a, float b, int32_t mode,
+                              void* stream) {
+    SVR2_CHECK(x && y && out, SVR2_E_ARG, "svr2_noise_mix: null pointer");
+    SVR2_CHECK(n > 0 && mode >= 0 && mode <= 2, SVR2_E_SHAPE, "svr2_noise_mix: bad size or mode");
+    hipLaunchKernelGGL(noise_mix_kernel, dim3(grid_1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)y,
+                       (bf16*)out, (long long)n, a, b, mode);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

@@ -83,7 +83,7 @@ EXPORTS = [
     "svr2_tile_accumulate", "svr2_tile_normalize",
     "svr2_alpha_stats", "svr2_alpha_guide", "svr2_alpha_sobel", "svr2_alpha_edges", "svr2_resize_plane",
     "svr2_guided_ab", "svr2_guided_out", "svr2_alpha_refine",
-    "svr2_jpeg_ws_bytes", "svr2_jpeg_encode",
+    "svr2_jpeg_ws_bytes", "svr2_jpeg_encode", "svr2_noise_mix",
 ]
 
 
@@ -706,6 +706,18 @@ def yuv_to_frames(raw: torch.Tensor, out: torch.Tensor, sub: int, frame_stride: 
     _u8c(raw, "yuv_to_frames.raw", T * frame_stride)
     _check(lib().svr2_yuv_to_frames(_p(raw), _p(out), C.c_int32(T), C.c_int32(H), C.c_int32(W), C.c_int32(sub),
                                     C.c_int64(frame_stride), _stream()), "svr2_yuv_to_frames")
+    return out
+
+
+def noise_mix(x: torch.Tensor, y: torch.Tensor, a: float, b: float, mode: int) -> torch.Tensor:
+    """svr2_noise_mix on two bf16 device tensors of equal shape (see include/seedvr2_hip.h for the three modes)."""
+    _bf16c(x, "noise_mix.x")
+    _bf16c(y, "noise_mix.y")
+    if x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous():
+        raise HipError("noise_mix: x and y must be contiguous and of equal shape")
+    out = torch.empty_like(x)
+    _check(lib().svr2_noise_mix(_p(x), _p(y), _p(out), C.c_int64(x.numel()), C.c_float(a), C.c_float(b), C.c_int32(mode),
+                                _stream()), "svr2_noise_mix")
     return out
 
 

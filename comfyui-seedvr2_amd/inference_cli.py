@@ -154,7 +154,8 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
     def run(frames, prepend):
         return pkg.nodes.SeedVR2VideoUpscaler.run_device(
             frames, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
-            a.temporal_overlap, prepend, a.color_correction, text_pos=text_pos)
+            a.temporal_overlap, prepend, a.color_correction, text_pos=text_pos, input_noise_scale=a.input_noise_scale,
+            latent_noise_scale=a.latent_noise_scale)
 
     def sink_for(w, h):
         return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image",

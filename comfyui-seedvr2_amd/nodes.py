@@ -108,12 +108,13 @@ class SeedVR2VideoUpscaler(_Base):
         if color_correction not in ("none",) + tuple(hip.COLOR_METHODS):
             raise NotImplementedError(f"color_correction '{color_correction}' is not implemented "
                                       f"(available: none, {', '.join(hip.COLOR_METHODS)})")
-        if input_noise_scale or latent_noise_scale:
-            raise NotImplementedError("noise injection scales other than 0 are not implemented")
+        if not (0.0 <= input_noise_scale <= 1.0 and 0.0 <= latent_noise_scale <= 1.0):
+            raise ValueError("input_noise_scale and latent_noise_scale must lie in [0, 1]")
         if batch_size % 4 != 1:
             raise ValueError("batch_size must follow 4n+1")
         out = cls.run_device(image, dit, vae, seed, resolution, max_resolution, batch_size, uniform_batch_size,
-                             temporal_overlap, prepend_frames, color_correction, text_pos=text_pos, pipeline=pipeline)
+                             temporal_overlap, prepend_frames, color_correction, text_pos=text_pos, pipeline=pipeline,
+                             input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale)
         return (out.float().cpu(),)
 
     @staticmethod
@@ -133,7 +134,8 @@ class SeedVR2VideoUpscaler(_Base):
     def run_device(cls, image: torch.Tensor, dit: dict, vae: dict, seed: int = 42, resolution: int = 1080,
                    max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
                    temporal_overlap: int = 0, prepend_frames: int = 0, color_correction: str = "lab",
-                   text_pos: torch.Tensor | None = None, pipeline=None) -> torch.Tensor:
+                   text_pos: torch.Tensor | None = None, pipeline=None, input_noise_scale: float = 0.0,
+                   latent_noise_scale: float = 0.0) -> torch.Tensor:
         """The upscaler without the host round trip: image [N,H,W,3] in [0,1] (any device / float dtype; bf16 frames that
         are already on the device are used as they are) -> bf16 [N,H',W',3] in [0,1] on the device."""
         pipe = pipeline or _build_pipeline(dit, vae, text_pos)
@@ -142,7 +144,8 @@ class SeedVR2VideoUpscaler(_Base):
                                                "decode_tile_size", "decode_tile_overlap") if k in (vae or {})})
         frames = cls.prepend_reversed(image, prepend_frames)
         out = pipe.generate(frames, resolution, batch_size, temporal_overlap, seed, max_resolution, uniform_batch_size,
-                            progress=_check_interrupt, color_correction=color_correction)
+                            progress=_check_interrupt, color_correction=color_correction,
+                            input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale)
         # postprocess_all_batches removes them again [ref: src/core/generation_phases.py:1377-1386]
         if prepend_frames > 0 and prepend_frames < out.shape[0]:
             out = out[prepend_frames:]

@@ -174,24 +174,72 @@ class SeedVR2Pipeline:
         g = torch.Generator(device="cpu").manual_seed(int(seed))
         return torch.randn(tuple(latent_shape), generator=g, dtype=torch.bfloat16, device="cpu")
 
+    @staticmethod
+    def blur_coefficients(latent_shape, scale: float, T: float = 1000.0) -> Tuple[float, float]:
+        """(A, B) of x_t = A*latent + B*aug_noise for latent_noise_scale [ref: generation_phases.py:684-693; infer.py:260-290;
+        schedules/lerp.py]: t = bf16(1000)*scale, resolution-dependent shift of `timestep_transform` fed -- as the reference
+        does -- with the channels-last latent's shape[1:] = (h, w, 16) in the (frames, height, width) slots, fp32 from the
+        shift on.  A handful of scalar torch ops on the host, with the reference's dtype promotions."""
+        t = torch.tensor([1000.0], dtype=torch.bfloat16) * scale
+        shape = torch.tensor(tuple(latent_shape[1:]))[None]
+        frames, heights, widths = (shape[:, 0] - 1) * 4 + 1, shape[:, 1] * 8, shape[:, 2] * 8
+
+        def lin(x1, y1, x2, y2):
+            m = (y2 - y1) / (x2 - x1)
+            b = y1 - m * x1
+            return lambda x: m * x + b
+
+        img, vid = lin(256 * 256, 1.0, 1024 * 1024, 3.2), lin(256 * 256 * 37, 1.0, 1280 * 720 * 145, 5.0)
+        shift = torch.where(frames > 1, vid(heights * widths * frames), img(heights * widths))
+        t = t / T
+        t = shift * t / (1 + (shift - 1) * t)
+        t = t * T
+        return float(1 - (t / T)), float(t / T)
+
     def upscale_batch(self, lr_frames: torch.Tensor, resolution: int, seed: int, max_resolution: int = 0,
-                      noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """lr_frames bf16 [T(4n+1),Hin,Win,3] on the device -> decoded bf16 [T,Hp,Wp,3] in ~[-1,1]."""
+                      noise: Optional[torch.Tensor] = None, input_noise_scale: float = 0.0,
+                      latent_noise_scale: float = 0.0, vae_generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """lr_frames bf16 [T(4n+1),Hin,Win,3] on the device -> decoded bf16 [T,Hp,Wp,3] in ~[-1,1].
+        input_noise_scale / latent_noise_scale: the reference's optional noise injections; the random numbers come from the
+        CPU generators the reference's CPU path uses (seed + 1 000 000 once per clip for the input noise, `seed` per batch
+        for base + aug noise), so results are reproducible against the oracle (a 4K batch draws 0.5 G numbers on the
+        host: seconds -- these knobs are off by default)."""
         x = self.transform(lr_frames, resolution, max_resolution)
+        if input_noise_scale > 0:
+            g = vae_generator or torch.Generator(device="cpu").manual_seed(int(seed) + 1000000)
+            T_, Hp, Wp, _ = x.shape
+            nz = torch.randn((3, T_, Hp, Wp), generator=g, dtype=torch.bfloat16)       # randn_like([C,T,H,W]) of the reference
+            nz = nz.permute(1, 2, 3, 0).contiguous().to(self.device)
+            bf_ = input_noise_scale * 0.5
+            x = hip.noise_mix(x, nz, 1 - bf_, bf_, 0)
+            del nz
         latent = self.vae.encode(x, **self.encode_tiling)
         del x
+        second = None
         if noise is None:
-            noise = self.make_noise(latent.shape, seed)
+            g = torch.Generator(device="cpu").manual_seed(int(seed))
+            noise = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16, device="cpu")
+            if latent_noise_scale > 0:
+                second = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16, device="cpu")
+        elif latent_noise_scale > 0:
+            raise hip.HipError("latent_noise_scale needs the pipeline's own noise (base and aug noise share a generator)")
         noise = noise.to(self.device).contiguous()
-        x0 = self.dit.one_step(noise, latent, self.text_pos)
-        del latent, noise
+        cond = latent
+        if latent_noise_scale > 0:
+            aug = hip.noise_mix(noise, second.to(self.device).contiguous(), 0.1, 0.05, 1)
+            a_, b_ = self.blur_coefficients(latent.shape, latent_noise_scale)
+            cond = hip.noise_mix(latent, aug, a_, b_, 2)
+            del aug
+        x0 = self.dit.one_step(noise, cond, self.text_pos)
+        del latent, noise, cond
         return self.vae.decode(x0, **self.decode_tiling)
 
     # whole clip ----------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, frames: torch.Tensor, resolution: int, batch_size: int = 5, temporal_overlap: int = 0,
                  seed: int = 42, max_resolution: int = 0, uniform_batch_size: bool = False,
-                 progress=None, color_correction: str = "none") -> torch.Tensor:
+                 progress=None, color_correction: str = "none", input_noise_scale: float = 0.0,
+                 latent_noise_scale: float = 0.0) -> torch.Tensor:
         """frames [N,Hin,Win,C] float in [0,1] (any device), C = 3 or 4 -> bf16 [N,true_h,true_w,C] in [0,1] on the device.
         color_correction: 'none' or one of hip.COLOR_METHODS (phase 4, against the transformed input of each batch
         [ref: src/core/generation_phases.py:1237-1304]).  RGBA: the colour channels take the normal path, the alpha plane
@@ -214,10 +262,13 @@ class SeedVR2Pipeline:
         final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16, device=self.device)
         w_prev = blend_weights(overlap).to(self.device) if overlap else None
         write = 0
+        g_vae = torch.Generator(device="cpu").manual_seed(int(seed) + 1000000)   # [ref: generation_phases.py:325-326]
         written = []   # (first frame, end frame, batch, frames of the batch that went into the previous slice)
         for bi, b in enumerate(batches):
             idx = torch.tensor(b.index, device=self.device)
-            dec = self.upscale_batch(src.index_select(0, idx).contiguous(), resolution, seed, max_resolution)
+            dec = self.upscale_batch(src.index_select(0, idx).contiguous(), resolution, seed, max_resolution,
+                                     input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale,
+                                     vae_generator=g_vae)
             sample = hip.crop_to_unit(dec[: b.ori_len].contiguous(), th, tw, to_unit=False)  # trim temporal+spatial pad
             del dec
             skipped = 0

@@ -370,6 +370,15 @@ int64_t svr2_jpeg_ws_bytes(int32_t T, int32_t H, int32_t W);
 int svr2_jpeg_encode(const void* frames, int32_t T, int32_t H, int32_t W, const int32_t* div, const uint32_t* huff,
                      void* packed, int64_t frame_cap, int32_t* frame_len, void* workspace, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ optional noise injection (node inputs / CLI flags)
+ * x, y, out bf16 [n]; scalars as torch applies python floats / fp32 scalar tensors to bf16 tensors.
+ *   mode 0: input_noise_scale [ref: src/core/generation_phases.py:409-425]: n = y*0.05 ; out = x*a + (x+n)*b with a = 1-s/2,
+ *           b = s/2, every op rounded to bf16 (x = transformed video, y = randn_like(x)).
+ *   mode 1: aug noise [ref: :679]: out = x*a + y*b rounded per op (a = 0.1, b = 0.05; x = base noise, y = second randn).
+ *   mode 2: latent_noise_scale, schedule.forward with an fp32 timestep [ref: :684-693; schedules/base.py:82-87]:
+ *           out = bf16(fp32(a*x) + fp32(b*y)), a = 1 - t/T, b = t/T. */
+int svr2_noise_mix(const void* x, const void* y, void* out, int64_t n, float a, float b, int32_t mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -459,6 +459,18 @@ def main():
     at["G14.binary.edges"] = edges_ref
     save_file({k: v.contiguous() for k, v in at.items()}, os.path.join(GOLD, "alpha_pins.safetensors"))
 
+    # ------------------------------------------------------------------ G15 latent blur = schedule.forward (noise knobs)
+    from src.common.diffusion.schedules.lerp import LinearInterpolationSchedule
+    from seedvr2_ref import pipeline as opipe
+    sch = LinearInterpolationSchedule(T=1000.0)
+    g = torch.Generator().manual_seed(95)
+    lat = torch.randn(2, 4, 6, 16, generator=g).to(torch.bfloat16)
+    n1, n2 = (torch.randn(2, 4, 6, 16, generator=g).to(torch.bfloat16) for _ in range(2))
+    for sc in (0.1, 0.5, 1.0):
+        t = opipe.blur_timestep(lat.shape, sc)                     # timestep_transform lives in core/infer.py (not importable)
+        ref = sch.forward(lat, n1 * 0.1 + n2 * 0.05, t).to(torch.bfloat16)
+        check(f"G15 latent_blur scale {sc}", opipe.latent_blur(lat, n1, n2, sc).float(), ref.float(), 0.0)
+
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(GOLD, "dit_pins.safetensors"))
     with open(os.path.join(GOLD, "dit_pins.json"), "w") as fh:
         json.dump(meta, fh)

@@ -94,9 +94,55 @@ def make_noise(shape, seed):
     return torch.randn(tuple(shape), generator=g, dtype=torch.bfloat16, device="cpu")
 
 
+def apply_input_noise(x: torch.Tensor, noise: torch.Tensor, scale: float) -> torch.Tensor:
+    """generation_phases.py:409-425: x = transformed video (bf16), noise = randn_like(x)."""
+    noise = noise * 0.05
+    blend_factor = scale * 0.5
+    return x * (1 - blend_factor) + (x + noise) * blend_factor
+
+
+def timestep_transform(timesteps: torch.Tensor, latents_shapes: torch.Tensor, T: float = 1000.0) -> torch.Tensor:
+    """core/infer.py:260-290 with `timesteps.transform: True` (configs_3b/main.yaml:80), vt = 4, vs = 8."""
+    frames = (latents_shapes[:, 0] - 1) * 4 + 1
+    heights = latents_shapes[:, 1] * 8
+    widths = latents_shapes[:, 2] * 8
+
+    def lin(x1, y1, x2, y2):
+        m = (y2 - y1) / (x2 - x1)
+        b = y1 - m * x1
+        return lambda x: m * x + b
+
+    img, vid = lin(256 * 256, 1.0, 1024 * 1024, 3.2), lin(256 * 256 * 37, 1.0, 1280 * 720 * 145, 5.0)
+    shift = torch.where(frames > 1, vid(heights * widths * frames), img(heights * widths))
+    timesteps = timesteps / T
+    timesteps = shift * timesteps / (1 + (shift - 1) * timesteps)
+    return timesteps * T
+
+
+def latent_blur(latent: torch.Tensor, base_noise: torch.Tensor, second_noise: torch.Tensor, scale: float,
+                T: float = 1000.0) -> torch.Tensor:
+    """generation_phases.py:676-701: aug noise = base*0.1 + randn*0.05; t = 1000*scale through timestep_transform with
+    the latent's shape[1:] -- the latent is channels-last [T_l,h,w,16] there, so the reference feeds (h, w, 16) where
+    (frames, height, width) are expected; restated as it is -- then schedule.forward (schedules/base.py:82-87) and the
+    cast into the bf16 condition tensor (infer.py:54-78)."""
+    if scale == 0.0:
+        return latent
+    aug = base_noise * 0.1 + second_noise * 0.05
+    t = blur_timestep(latent.shape, scale, latent.dtype, T)
+    t = t.view(-1, *([1] * (latent.ndim - 1)))                       # expand_dims(t, x_0.ndim)
+    return ((1 - (t / T)) * latent + (t / T) * aug).to(latent.dtype)
+
+
+def blur_timestep(latent_shape, scale: float, dtype=torch.bfloat16, T: float = 1000.0) -> torch.Tensor:
+    """The (shifted) timestep of latent_blur: fp32 [1]."""
+    t = torch.tensor([1000.0], dtype=dtype) * scale
+    return timestep_transform(t, torch.tensor(tuple(latent_shape[1:]))[None], T)
+
+
 def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, resolution: int, batch_size: int = 5,
              temporal_overlap: int = 0, seed: int = 42, dtype=torch.float32, uniform_batch_size: bool = False,
-             taps: dict | None = None, color_correction: str = "none") -> torch.Tensor:
+             taps: dict | None = None, color_correction: str = "none", input_noise_scale: float = 0.0,
+             latent_noise_scale: float = 0.0) -> torch.Tensor:
     """frames [N,H,W,3] float in [0,1] -> [N,true_h,true_w,3] in [0,1] (dtype bf16 storage between phases,
     model arithmetic in `dtype`)."""
     N, H, W, _ = frames.shape
@@ -106,6 +152,7 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
     final = torch.empty(N, th, tw, 3, dtype=torch.bfloat16)
     write = 0
     written = []
+    g_vae = torch.Generator(device="cpu").manual_seed(int(seed) + 1000000)     # generation_phases.py:325-326
     for bi, (s, e) in enumerate(ranges):
         vid = src[s:e]
         ori = e - s
@@ -113,9 +160,15 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
             vid = pad_video_temporal(vid, batch_size - ori)
         vid = pad_video_temporal(vid)                                   # 4n+1
         x = transform(vid.permute(0, 3, 1, 2), resolution)             # [3,T,Hp,Wp] bf16
-        latent = _vae.encode(vae_p, x.float() if dtype == torch.float32 else x, vae_cfg, dtype).to(torch.bfloat16)
-        noise = make_noise(latent.shape, seed)
-        x0 = _dit.one_step_sr(dit_p, dit_cfg, latent.to(dtype), noise.to(dtype), text_pos.to(dtype), dtype)
+        x_in = x
+        if input_noise_scale > 0:                                      # the colour reference below stays noise-free
+            x_in = apply_input_noise(x, torch.randn(x.shape, generator=g_vae, dtype=torch.bfloat16), input_noise_scale)
+        latent = _vae.encode(vae_p, x_in.float() if dtype == torch.float32 else x_in, vae_cfg, dtype).to(torch.bfloat16)
+        g = torch.Generator(device="cpu").manual_seed(int(seed))        # set_seed(seed) per batch (:659)
+        noise = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16)
+        second = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16)   # always drawn (:679)
+        cond_latent = latent_blur(latent, noise, second, latent_noise_scale)
+        x0 = _dit.one_step_sr(dit_p, dit_cfg, cond_latent.to(dtype), noise.to(dtype), text_pos.to(dtype), dtype)
         x0 = x0.to(torch.bfloat16)
         dec = _vae.decode(vae_p, x0.to(dtype), vae_cfg, dtype).to(torch.bfloat16)   # [3,T,Hp,Wp]
         if taps is not None and bi == 0:

@@ -142,3 +142,29 @@ def test_color_oracle_matches_reference_golden():
     out = ocol.histogram_match(src, ref)
     assert torch.equal(out.flatten().sort().values, ref.flatten().sort().values)
     assert torch.equal(out.flatten().argsort(), src.flatten().argsort())
+
+
+def test_oracle_noise_injection_semantics():
+    """input noise / latent blur of the oracle: identity at scale 0, the reference's dtype flow (bf16 in, bf16 out, fp32
+    timestep), the (h, w, 16)-as-(frames, height, width) quirk of the shift, and schedule.forward's lerp."""
+    from seedvr2_ref import pipeline as opipe
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 5, 8, 8, generator=g).to(torch.bfloat16)
+    n = torch.randn(3, 5, 8, 8, generator=g).to(torch.bfloat16)
+    y = opipe.apply_input_noise(x, n, 0.5)
+    assert y.dtype == torch.bfloat16 and (y.float() - x.float()).abs().max() < 0.25 * 0.05 * 5 + 0.02
+    lat = torch.randn(2, 4, 6, 16, generator=g).to(torch.bfloat16)
+    b1, b2 = (torch.randn(2, 4, 6, 16, generator=g).to(torch.bfloat16) for _ in range(2))
+    assert opipe.latent_blur(lat, b1, b2, 0.0) is lat
+    t = opipe.blur_timestep(lat.shape, 0.3)
+    assert t.dtype == torch.float32 and t.shape == (1,)
+    # shift from (frames, h, w) = ((4-1)*4+1, 6*8, 16*8): vid branch
+    m = (5.0 - 1.0) / (1280 * 720 * 145 - 256 * 256 * 37)
+    shift = m * (48 * 128 * 13) + (1.0 - m * 256 * 256 * 37)
+    t0 = float((torch.tensor([1000.0], dtype=torch.bfloat16) * 0.3) / 1000.0)     # still bf16 here: 0.30078125
+    assert t0 == 0.30078125
+    assert abs(float(t) / 1000.0 - shift * t0 / (1 + (shift - 1) * t0)) < 1e-6
+    out = opipe.latent_blur(lat, b1, b2, 0.3)
+    aug = b1 * 0.1 + b2 * 0.05
+    want = ((1 - t / 1000.0) * lat.float() + (t / 1000.0) * aug.float()).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, want)

@@ -236,6 +236,57 @@ def test_pipeline_end_to_end_psnr(pkg, gpu, cc):
     assert p_hip >= p_b16 - 3.0 and p_hip > 30.0
 
 
+def test_noise_mix_kernels_match_torch_ops(pkg, gpu):
+    """svr2_noise_mix against the torch expressions of the reference (bf16 tensors, python-float / fp32-tensor scalars),
+    bit for bit, on 200 k random values plus extremes."""
+    from seedvr2_ref import pipeline as opipe
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat((torch.randn(200000, generator=g) * 1.5, torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30]))).to(torch.bfloat16)
+    y = torch.cat((torch.randn(200000, generator=g), torch.tensor([1.0, -1.0, 0.0, 2.0, 1.0, -1.0, 1e-30]))).to(torch.bfloat16)
+    xd, yd = x.to(gpu), y.to(gpu)
+    for s in (0.25, 0.5, 1.0, 0.1):
+        want = opipe.apply_input_noise(x, y, s)
+        got = pkg.hip.noise_mix(xd, yd, 1 - s * 0.5, s * 0.5, 0).cpu()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), s
+    want = x * 0.1 + y * 0.05
+    assert torch.equal(pkg.hip.noise_mix(xd, yd, 0.1, 0.05, 1).cpu().view(torch.int16), want.view(torch.int16))
+    for s, shape in ((0.3, (3, 4, 6, 16)), (1.0, (6, 270, 480, 16)), (0.05, (1, 64, 64, 16))):
+        a, b = pkg.pipeline.SeedVR2Pipeline.blur_coefficients(shape, s)
+        t = opipe.blur_timestep(shape, s)
+        assert a == float(1 - t / 1000.0) and b == float(t / 1000.0) and 0 < b <= 1
+        tt = t.view(1)
+        want = ((1 - (tt / 1000.0)) * x + (tt / 1000.0) * y).to(torch.bfloat16)
+        assert torch.equal(pkg.hip.noise_mix(xd, yd, a, b, 2).cpu().view(torch.int16), want.view(torch.int16)), (s, shape)
+
+
+def test_pipeline_with_noise_injection_psnr(pkg, gpu):
+    """input_noise_scale / latent_noise_scale: same CPU random streams as the oracle (seed + 1 000 000 per clip, seed per
+    batch), so the HIP path still tracks the fp32 oracle; and the knobs do change the result."""
+    from seedvr2_ref import dit as odit, pipeline as opipe
+    ovae, ocfg, vp, vae = _vae_pair(pkg, gpu, seed=1)
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=2, mm_layers=1, txt_in_dim=64, mlp_multiple_of=64)
+    dcfg = odit.DiTConfig(**kw)
+    dp = {k: bf(v) for k, v in odit.synthetic_params(dcfg, 2).items()}
+    dit = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(**kw), dp, gpu)
+    txt = bf(torch.randn(58, 64, generator=torch.Generator().manual_seed(8)))
+    lr = torch.rand(7, 4, 6, 3, generator=torch.Generator().manual_seed(9))
+    lr = F.interpolate(lr.permute(0, 3, 1, 2), size=(16, 24), mode="bicubic").permute(0, 2, 3, 1).clamp(0, 1)
+    lr = (lr * 255).round() / 255
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    kwn = dict(input_noise_scale=0.6, latent_noise_scale=0.4)
+    got = pipe.generate(lr, resolution=32, batch_size=5, temporal_overlap=2, seed=42, **kwn).float().cpu()
+    plain = pipe.generate(lr, resolution=32, batch_size=5, temporal_overlap=2, seed=42).float().cpu()
+    ref32 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.float32, **kwn).float()
+    ref16 = opipe.generate(lr, vp, ocfg, dp, dcfg, txt, 32, 5, 2, 42, torch.bfloat16, **kwn).float()
+    p_hip, p_b16, p_plain = psnr(got, ref32), psnr(ref16, ref32), psnr(plain, ref32)
+    print(f"noise injection: PSNR vs fp32 oracle hip={p_hip:.2f} dB, bf16 oracle={p_b16:.2f} dB; without the knobs {p_plain:.2f} dB")
+    assert p_hip >= p_b16 - 3.0 and p_hip > 30.0 and p_plain < p_hip - 3.0
+    node, = pkg.nodes.SeedVR2VideoUpscaler.execute(lr, {}, {}, 42, 32, 0, 5, False, 2, 0, "none", 0.6, 0.4, pipeline=pipe)
+    assert torch.equal(node, got)
+    with pytest.raises(ValueError):
+        pkg.nodes.SeedVR2VideoUpscaler.execute(lr, {}, {}, 42, 32, 0, 5, False, 2, 0, "none", 1.5, 0.0, pipeline=pipe)
+
+
 def test_runner_seam_and_node(pkg, gpu):
     """The reference-shaped runner (vae_encode -> get_condition -> inference -> vae_decode) and the ComfyUI
     node give the same pixels as the fused pipeline (same kernels underneath, no fallback path)."""
