@@ -45,6 +45,99 @@ def _check_interrupt(done: int = 0, total: int = 0) -> None:
     mm.throw_exception_if_processing_interrupted()
 
 
+# ComfyUI V3 schemas: same node ids, input names, kinds, defaults, ranges and option lists as the reference
+# [ref: src/interfaces/video_upscaler.py:48-222, dit_model_loader.py:30-130, vae_model_loader.py:31-165,
+#  torch_compile_settings.py:13-97]; (name, io kind, keyword arguments)
+_DEVICES = ["cuda:0", "cuda:1", "cuda:2", "cuda:3", "cuda:4", "cuda:5", "cuda:6", "cuda:7"]
+_OFFLOAD = ["none", "cpu"] + _DEVICES
+_SCHEMAS = {
+    "SeedVR2VideoUpscaler": dict(
+        display_name="SeedVR2 Video Upscaler (MI355X)",
+        description="One-step SeedVR2 upscaling of an image batch (RGB or RGBA) on the MI355X-native path.",
+        inputs=[
+            ("image", "Image", dict(tooltip="Frames [N,H,W,3|4] in [0,1]; the output keeps the channel count.")),
+            ("dit", "Custom:SEEDVR2_DIT", dict(tooltip="From SeedVR2 (Down)Load DiT Model.")),
+            ("vae", "Custom:SEEDVR2_VAE", dict(tooltip="From SeedVR2 (Down)Load VAE Model.")),
+            ("seed", "Int", dict(default=42, min=0, max=2 ** 32 - 1, step=1, tooltip="Noise seed; same seed, same output.")),
+            ("resolution", "Int", dict(default=1080, min=16, max=16384, step=2, tooltip="Target length of the shortest edge.")),
+            ("max_resolution", "Int", dict(default=0, min=0, max=16384, step=2, tooltip="Cap for the longest edge (0 = none).")),
+            ("batch_size", "Int", dict(default=5, min=1, max=16384, step=4, tooltip="Frames per batch, 4n+1.")),
+            ("uniform_batch_size", "Boolean", dict(default=False, tooltip="Pad the last batch to batch_size.")),
+            ("temporal_overlap", "Int", dict(default=0, min=0, max=16, step=1, tooltip="Frames cross-faded between batches.")),
+            ("prepend_frames", "Int", dict(default=0, min=0, max=32, step=1, tooltip="Reversed head frames as warm-up context.")),
+            ("color_correction", "Combo", dict(options=["lab", "wavelet", "wavelet_adaptive", "hsv", "adain", "none"], default="lab",
+                                              tooltip="Phase-4 colour matching against the input.")),
+            ("input_noise_scale", "Float", dict(default=0.0, min=0.0, max=1.0, step=0.001, tooltip="Noise blended into the model input.")),
+            ("latent_noise_scale", "Float", dict(default=0.0, min=0.0, max=1.0, step=0.001, tooltip="Noise blended into the condition latent.")),
+            ("offload_device", "Combo", dict(options=_OFFLOAD, default="cpu", tooltip="Accepted for compatibility; nothing is offloaded.")),
+            ("enable_debug", "Boolean", dict(default=False, tooltip="Accepted for compatibility.")),
+        ],
+        outputs=[("Image", dict(tooltip="Upscaled frames, float32 [N,H',W',C] in [0,1]."))]),
+    "SeedVR2LoadDiTModel": dict(
+        display_name="SeedVR2 (Down)Load DiT Model",
+        description="Selects the NaDiT checkpoint (3B / 7B .safetensors under models/SEEDVR2) and its device.",
+        inputs=[
+            ("model", "Combo", dict(options=list(_weights.DIT_MODELS), default=_weights.DEFAULT_DIT, tooltip="Checkpoint file name.")),
+            ("device", "Combo", dict(options=_DEVICES, default=_DEVICES[0], tooltip="GPU that runs the model.")),
+            ("blocks_to_swap", "Int", dict(default=0, min=0, max=36, step=1, optional=True, tooltip="Must stay 0: 288 GB of HBM need no BlockSwap.")),
+            ("swap_io_components", "Boolean", dict(default=False, optional=True, tooltip="Must stay off.")),
+            ("offload_device", "Combo", dict(options=_OFFLOAD, default="none", optional=True, tooltip="Accepted; nothing is offloaded.")),
+            ("cache_model", "Boolean", dict(default=False, optional=True, tooltip="Models stay resident between runs either way.")),
+            ("attention_mode", "Combo", dict(options=["sdpa", "flash_attn"], default="sdpa", optional=True,
+                                            tooltip="Accepted; the window attention always runs the HIP flash kernel.")),
+            ("torch_compile_args", "Custom:TORCH_COMPILE_ARGS", dict(optional=True, tooltip="Accepted; there is no tracing compiler here.")),
+        ],
+        outputs=[("Custom:SEEDVR2_DIT", dict(tooltip="DiT configuration."))]),
+    "SeedVR2LoadVAEModel": dict(
+        display_name="SeedVR2 (Down)Load VAE Model",
+        description="Selects the VAE checkpoint, its device and the optional spatial tiling.",
+        inputs=[
+            ("model", "Combo", dict(options=[_weights.DEFAULT_VAE], default=_weights.DEFAULT_VAE, tooltip="Checkpoint file name.")),
+            ("device", "Combo", dict(options=_DEVICES, default=_DEVICES[0], tooltip="GPU that runs the model.")),
+            ("encode_tiled", "Boolean", dict(default=False, optional=True, tooltip="Encode in blended spatial tiles.")),
+            ("encode_tile_size", "Int", dict(default=1024, min=64, step=32, optional=True, tooltip="Tile edge in pixels.")),
+            ("encode_tile_overlap", "Int", dict(default=128, min=0, step=32, optional=True, tooltip="Blend width in pixels.")),
+            ("decode_tiled", "Boolean", dict(default=False, optional=True, tooltip="Decode in blended spatial tiles.")),
+            ("decode_tile_size", "Int", dict(default=1024, min=64, step=32, optional=True, tooltip="Tile edge in output pixels.")),
+            ("decode_tile_overlap", "Int", dict(default=128, min=0, step=32, optional=True, tooltip="Blend width in output pixels.")),
+            ("tile_debug", "Combo", dict(options=["false", "encode", "decode"], default="false", optional=True, tooltip="Must stay 'false'.")),
+            ("offload_device", "Combo", dict(options=_OFFLOAD, default="none", optional=True, tooltip="Accepted; nothing is offloaded.")),
+            ("cache_model", "Boolean", dict(default=False, optional=True, tooltip="Models stay resident between runs either way.")),
+            ("torch_compile_args", "Custom:TORCH_COMPILE_ARGS", dict(optional=True, tooltip="Accepted; there is no tracing compiler here.")),
+        ],
+        outputs=[("Custom:SEEDVR2_VAE", dict(tooltip="VAE configuration."))]),
+    "SeedVR2TorchCompileSettings": dict(
+        display_name="SeedVR2 Torch Compile Settings",
+        description="Kept so that existing graphs load; the settings are carried along and ignored.",
+        inputs=[
+            ("backend", "Combo", dict(options=["inductor", "cudagraphs"], default="inductor", tooltip="Ignored.")),
+            ("mode", "Combo", dict(options=["default", "reduce-overhead", "max-autotune", "max-autotune-no-cudagraphs"], default="default",
+                                  tooltip="Ignored.")),
+            ("fullgraph", "Boolean", dict(default=False, tooltip="Ignored.")),
+            ("dynamic", "Boolean", dict(default=False, tooltip="Ignored.")),
+            ("dynamo_cache_size_limit", "Int", dict(default=64, min=0, max=1024, step=1, tooltip="Ignored.")),
+            ("dynamo_recompile_limit", "Int", dict(default=128, min=0, max=1024, step=1, tooltip="Ignored.")),
+        ],
+        outputs=[("Custom:TORCH_COMPILE_ARGS", dict(tooltip="Settings dictionary."))]),
+}
+
+
+def _io_kind(kind: str):
+    return io.Custom(kind.split(":", 1)[1]) if kind.startswith("Custom:") else getattr(io, kind)
+
+
+def _schema(node_id: str):
+    spec = _SCHEMAS[node_id]
+    return io.Schema(node_id=node_id, display_name=spec["display_name"], category="SEEDVR2", description=spec["description"],
+                     inputs=[_io_kind(k).Input(n, **kw) for n, k, kw in spec["inputs"]],
+                     outputs=[_io_kind(k).Output(**kw) for k, kw in spec["outputs"]])
+
+
+def _out(value):
+    """Node result: io.NodeOutput inside ComfyUI [ref: dit_model_loader.py:183], a 1-tuple standalone."""
+    return io.NodeOutput(value) if io is not None else (value,)
+
+
 def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pipeline.SeedVR2Pipeline:
     key = (dit_cfg["model"], vae_cfg["model"], dit_cfg["device"])
     if key not in _PIPELINES:
@@ -63,6 +156,10 @@ def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pi
 
 class SeedVR2LoadDiTModel(_Base):
     @classmethod
+    def define_schema(cls):
+        return _schema("SeedVR2LoadDiTModel")
+
+    @classmethod
     def execute(cls, model: str = _weights.DEFAULT_DIT, device: str = "cuda:0", offload_device: str = "none",
                 cache_model: bool = False, blocks_to_swap: int = 0, swap_io_components: bool = False,
                 attention_mode: str = "sdpa", torch_compile_args=None, node_id=None):
@@ -70,10 +167,14 @@ class SeedVR2LoadDiTModel(_Base):
             raise ValueError("BlockSwap is not needed on 288 GB HBM; set blocks_to_swap=0")
         cfg = dict(zip(DIT_KEYS, (model, device, offload_device, cache_model, 0, False, attention_mode,
                                   torch_compile_args, node_id)))
-        return (cfg,)
+        return _out(cfg)
 
 
 class SeedVR2LoadVAEModel(_Base):
+    @classmethod
+    def define_schema(cls):
+        return _schema("SeedVR2LoadVAEModel")
+
     @classmethod
     def execute(cls, model: str = _weights.DEFAULT_VAE, device: str = "cuda:0", offload_device: str = "none",
                 cache_model: bool = False, encode_tiled: bool = False, encode_tile_size: int = 1024,
@@ -85,16 +186,24 @@ class SeedVR2LoadVAEModel(_Base):
         cfg = dict(zip(VAE_KEYS, (model, device, offload_device, cache_model, bool(encode_tiled), encode_tile_size,
                                   encode_tile_overlap, bool(decode_tiled), decode_tile_size, decode_tile_overlap, tile_debug,
                                   torch_compile_args, node_id)))
-        return (cfg,)
+        return _out(cfg)
 
 
 class SeedVR2TorchCompileSettings(_Base):
     @classmethod
+    def define_schema(cls):
+        return _schema("SeedVR2TorchCompileSettings")
+
+    @classmethod
     def execute(cls, **kwargs):
-        return (dict(kwargs),)  # accepted for graph compatibility; there is no tracing compiler on this path
+        return _out(dict(kwargs))  # accepted for graph compatibility; there is no tracing compiler on this path
 
 
 class SeedVR2VideoUpscaler(_Base):
+    @classmethod
+    def define_schema(cls):
+        return _schema("SeedVR2VideoUpscaler")
+
     @classmethod
     def execute(cls, image: torch.Tensor, dit: dict, vae: dict, seed: int = 42, resolution: int = 1080,
                 max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
@@ -115,7 +224,7 @@ class SeedVR2VideoUpscaler(_Base):
         out = cls.run_device(image, dit, vae, seed, resolution, max_resolution, batch_size, uniform_batch_size,
                              temporal_overlap, prepend_frames, color_correction, text_pos=text_pos, pipeline=pipeline,
                              input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale)
-        return (out.float().cpu(),)
+        return _out(out.float().cpu())
 
     @staticmethod
     def prepend_reversed(x: torch.Tensor, count: int) -> torch.Tensor:

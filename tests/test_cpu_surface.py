@@ -89,3 +89,55 @@ def test_vae_checkpoint_key_normalisation(pkg):
                                                                mlp_type="normal", out_norm=False, last_vid_only=False), "cpu")) == \
         set(odit.param_shapes(odit.DiTConfig(vid_dim=64, heads=2, head_dim=32, txt_in_dim=32, num_layers=2, mm_layers=2,
                                              mlp_type="normal", out_norm=False, last_vid_only=False)))
+
+
+def test_comfy_v3_schemas_mirror_the_reference_inputs(pkg, surface, monkeypatch):
+    """define_schema() (only used inside ComfyUI) builds io.Schema objects with the reference's node ids, input names and
+    defaults; checked here with a recording stand-in for comfy_api's `io`."""
+    N = pkg.nodes
+
+    class _Kind:
+        def __init__(self, name):
+            self.name = name
+
+        def Input(self, n, **kw):
+            return ("in", self.name, n, kw)
+
+        def Output(self, **kw):
+            return ("out", self.name, kw)
+
+    class _IO:
+        Image, Int, Float, Boolean, Combo = (_Kind(k) for k in ("Image", "Int", "Float", "Boolean", "Combo"))
+
+        @staticmethod
+        def Custom(tag):
+            return _Kind("Custom:" + tag)
+
+        @staticmethod
+        def Schema(**kw):
+            return kw
+
+        class NodeOutput(tuple):
+            def __new__(cls, *a):
+                return tuple.__new__(cls, a)
+
+    monkeypatch.setattr(N, "io", _IO)
+    up = N.SeedVR2VideoUpscaler.define_schema()
+    assert up["node_id"] == "SeedVR2VideoUpscaler" and up["category"] == "SEEDVR2"
+    assert [i[2] for i in up["inputs"]] == surface["upscaler_inputs"]
+    by = {i[2]: i for i in up["inputs"]}
+    assert by["batch_size"][3]["default"] == 5 and by["batch_size"][3]["step"] == 4 and by["color_correction"][3]["default"] == "lab"
+    assert by["color_correction"][3]["options"] == ["lab", "wavelet", "wavelet_adaptive", "hsv", "adain", "none"]
+    assert by["dit"][1] == "Custom:SEEDVR2_DIT" and up["outputs"][0][1] == "Image"
+    dit = N.SeedVR2LoadDiTModel.define_schema()
+    assert [i[2] for i in dit["inputs"]] == [k for k in N.DIT_KEYS if k != "node_id"][:2] + ["blocks_to_swap", "swap_io_components",
+                                                                                         "offload_device", "cache_model",
+                                                                                         "attention_mode", "torch_compile_args"]
+    assert dit["outputs"][0][1] == "Custom:SEEDVR2_DIT"
+    vae = N.SeedVR2LoadVAEModel.define_schema()
+    assert {i[2] for i in vae["inputs"]} == set(N.VAE_KEYS) - {"node_id"} and vae["outputs"][0][1] == "Custom:SEEDVR2_VAE"
+    tc = N.SeedVR2TorchCompileSettings.define_schema()
+    assert [i[2] for i in tc["inputs"]] == ["backend", "mode", "fullgraph", "dynamic", "dynamo_cache_size_limit", "dynamo_recompile_limit"]
+    # inside ComfyUI the nodes answer with io.NodeOutput
+    out = N.SeedVR2LoadVAEModel.execute(decode_tiled=True)
+    assert isinstance(out, _IO.NodeOutput) and out[0]["decode_tiled"] is True
