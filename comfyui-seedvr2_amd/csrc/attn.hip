@@ -27,6 +27,7 @@ constexpr float RESCALE_THR = 4.0f;  // log2 units: P stays <= 16 between rescal
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v; bf16* out;
     const int32_t* cu; const int32_t* tile_seq; const int32_t* tile_q0;
+    const int32_t* out_rows;   // optional: output row of every position (scatter, e.g. back to natural token order)
     long long ld, ldo;   // elements between consecutive positions (q/k/v and out)
     int fixed_len;       // > 0: sequences are frames of this length (cu/tile tables unused)
     float scale_log2;
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(co
     const float inv = 1.0f / l_tot;
     const int qr = q0 + wave * 32 + l31;
     if (qr < len) {
-        bf16* op = a.out + (s0 + qr) * a.ldo + hoff + 4 * hh;
+        const long long orow = a.out_rows ? (long long)a.out_rows[s0 + qr] : (long long)(s0 + qr);
+        bf16* op = a.out + orow * a.ldo + hoff + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -224,7 +226,7 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens,
+static int window_attn_impl(const void* q, const void* k, const void* v, void* out, const int32_t* out_rows, const int32_t* cu_seqlens,
                                 const int32_t* tile_seq, const int32_t* tile_q0, int32_t ntiles, int32_t H, int32_t D,
                                 float scale, void* stream) {
     SVR2_CHECK(q && k && v && out && cu_seqlens && tile_seq && tile_q0, SVR2_E_ARG, "svr2_window_attn: null pointer");
@@ -234,8 +236,21 @@ extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, voi
                "svr2_window_attn: pointers must be 16-byte aligned");
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
-    a.cu = cu_seqlens; a.tile_seq = tile_seq; a.tile_q0 = tile_q0;
+    a.cu = cu_seqlens; a.tile_seq = tile_seq; a.tile_q0 = tile_q0; a.out_rows = out_rows;
     a.ld = (long long)H * 128; a.ldo = a.ld; a.fixed_len = 0;
     a.scale_log2 = scale * 1.4426950408889634f;
     return launch_attn<128, 64>(a, dim3(ntiles, H, 1), (hipStream_t)stream);
+}
+
+extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens,
+                                const int32_t* tile_seq, const int32_t* tile_q0, int32_t ntiles, int32_t H, int32_t D,
+                                float scale, void* stream) {
+    return window_attn_impl(q, k, v, out, nullptr, cu_seqlens, tile_seq, tile_q0, ntiles, H, D, scale, stream);
+}
+
+extern "C" int svr2_window_attn_scatter(const void* q, const void* k, const void* v, void* out, const int32_t* out_rows,
+                                        const int32_t* cu_seqlens, const int32_t* tile_seq, const int32_t* tile_q0,
+                                        int32_t ntiles, int32_t H, int32_t D, float scale, void* stream) {
+    SVR2_CHECK(out_rows, SVR2_E_ARG, "svr2_window_attn_scatter: null out_rows");
+    return window_attn_impl(q, k, v, out, out_rows, cu_seqlens, tile_seq, tile_q0, ntiles, H, D, scale, stream);
 }

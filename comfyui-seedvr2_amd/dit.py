@@ -18,6 +18,7 @@ Weights are taken in the reference's state-dict layout.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Tuple
 
@@ -167,10 +168,19 @@ class NaDiTHip:
             if p.max_pos > self.rope_cos.shape[0]:
                 raise hip.HipError(f"rope table too small for position {p.max_pos}")
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            # the attention kernel scatters its rows: video rows back to natural token order (window_reverse), the
+            # replicated text rows behind them, so the output projection reads a dense [L, H*D] matrix
+            L = int(p.inv_rows.shape[0])
+            out_rows = np.full(p.total, -1, dtype=np.int32)
+            out_rows[p.inv_rows] = np.arange(L, dtype=np.int32)
+            txt_out0 = (L + np.arange(p.nwin, dtype=np.int64) * txt_len).astype(np.int32)
+            for w in range(p.nwin):
+                out_rows[p.txt_row0[w]:p.txt_row0[w] + txt_len] = txt_out0[w] + np.arange(txt_len, dtype=np.int32)
+            assert (np.sort(out_rows) == np.arange(p.total)).all()
             self._plans[key] = {
-                "S": p.total, "nwin": p.nwin, "src_row": up(p.src_row), "pos": up(p.pos), "cu": up(p.cu_seqlens),
+                "S": p.total, "L": L, "nwin": p.nwin, "src_row": up(p.src_row), "pos": up(p.pos), "cu": up(p.cu_seqlens),
                 "tile_seq": up(p.tile_seq), "tile_q0": up(p.tile_q0), "inv_rows": up(p.inv_rows),
-                "txt_row0": up(p.txt_row0),
+                "txt_row0": up(p.txt_row0), "out_rows": up(out_rows), "txt_out0": up(txt_out0),
             }
         return self._plans[key]
 
@@ -217,12 +227,21 @@ class NaDiTHip:
         qkvw = hip.qkv_prep(qkv_v, qkv_t, pl["src_row"], pl["pos"], Lv["qn"], Lv["kn"], Lt_["qn"], Lt_["kn"],
                             rc, rs, H, cfg.rope_mode, cfg.norm_eps)
         del qkv_v, qkv_t, xa, ya
-        o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D))
-        del qkvw
-        o2 = o.view(pl["S"], H * D)
-        ot = hip.txt_mean(o2, pl["txt_row0"], ntxt)
-        x1 = hip.gemm(o2, Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"], resid=x,
-                      a_rows=pl["inv_rows"], m=x.shape[0])
+        if os.environ.get("SVR2_DIT_SCATTER", "1") != "0":
+            o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D),
+                                out_rows=pl["out_rows"])
+            del qkvw
+            o2 = o.view(pl["S"], H * D)
+            ot = hip.txt_mean(o2, pl["txt_out0"], ntxt)
+            x1 = hip.gemm(o2[: pl["L"]], Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"],
+                          resid=x)
+        else:   # A/B: window-ordered attention output, row gather fused into the projection's A loads
+            o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D))
+            del qkvw
+            o2 = o.view(pl["S"], H * D)
+            ot = hip.txt_mean(o2, pl["txt_row0"], ntxt)
+            x1 = hip.gemm(o2, Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"], resid=x,
+                          a_rows=pl["inv_rows"], m=x.shape[0])
         y1 = hip.gemm(ot, Lt_["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lt_["b_out"], gate=Lt_["attn_gate"], resid=y)
         if taps is not None:
             taps["x1"] = x1; taps["y1"] = y1

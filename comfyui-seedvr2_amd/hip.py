@@ -72,7 +72,7 @@ _INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_matc
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
-    "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_txt_mean", "svr2_patch_in",
+    "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_window_attn_scatter", "svr2_txt_mean", "svr2_patch_in",
     "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
     "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles",
     "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
@@ -381,7 +381,7 @@ def qkv_prep(qkv_vid, qkv_txt, src_row, pos, qn_vid, kn_vid, qn_txt, kn_txt, rop
     return out
 
 
-def window_attn(q, k, v, cu_seqlens, tile_seq, tile_q0, scale: float, out=None):
+def window_attn(q, k, v, cu_seqlens, tile_seq, tile_q0, scale: float, out=None, out_rows=None):
     for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
         _bf16c(t_, "window_attn." + nm)
         if t_.dim() != 3 or t_.shape[2] != 128 or not t_.is_contiguous() or t_.shape != q.shape:
@@ -393,6 +393,13 @@ def window_attn(q, k, v, cu_seqlens, tile_seq, tile_q0, scale: float, out=None):
         raise HipError("window_attn: tile list mismatch")
     if out is None:
         out = torch.empty_like(q)
+    if out_rows is not None:   # result of position s goes to row out_rows[s] (a permutation of the S rows)
+        if out_rows.dtype != torch.int32 or not out_rows.is_cuda or out_rows.numel() != q.shape[0]:
+            raise HipError("window_attn: out_rows must be an int32 device tensor with one entry per position")
+        _check(lib().svr2_window_attn_scatter(_p(q), _p(k), _p(v), _p(out), _p(out_rows), _p(cu_seqlens), _p(tile_seq),
+                                              _p(tile_q0), C.c_int32(tile_seq.numel()), C.c_int32(q.shape[1]),
+                                              C.c_int32(128), C.c_float(scale), _stream()), "svr2_window_attn_scatter")
+        return out
     _check(lib().svr2_window_attn(_p(q), _p(k), _p(v), _p(out), _p(cu_seqlens), _p(tile_seq), _p(tile_q0),
                                   C.c_int32(tile_seq.numel()), C.c_int32(q.shape[1]), C.c_int32(128),
                                   C.c_float(scale), _stream()), "svr2_window_attn")

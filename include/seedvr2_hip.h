@@ -179,6 +179,12 @@ int svr2_qkv_prep(const svr2_qkv_prep_desc* d, void* stream);
 int svr2_window_attn(const void* q, const void* k, const void* v, void* out,
                      const int32_t* cu_seqlens, const int32_t* tile_seq, const int32_t* tile_q0,
                      int32_t ntiles, int32_t H, int32_t D, float scale, void* stream);
+/* Same, with the result of position s written to row out_rows[s] of `out` (int32 [S], a permutation of 0..S-1): lets
+ * the caller get the video rows back in natural token order (window_reverse, mmattn.py:260-264) so that the
+ * following projection is a dense GEMM instead of a row gather. */
+int svr2_window_attn_scatter(const void* q, const void* k, const void* v, void* out, const int32_t* out_rows,
+                             const int32_t* cu_seqlens, const int32_t* tile_seq, const int32_t* tile_q0,
+                             int32_t ntiles, int32_t H, int32_t D, float scale, void* stream);
 
 /* Mean over windows of the replicated text rows [ref: models/dit_3b/na.py:396-417]:
  * out[j, :] = mean_w attn[txt_row0[w] + j, :],  attn bf16 [S, dim]. */
