@@ -16,7 +16,7 @@ import sys
 FAMILIES = [
     ("conv3d halo-resident (conv_halo*_kernel)", lambda n: "conv_halo" in n),
     ("conv3d tap-staged (A_CONV of gemm.hip + gemm2.hip)", lambda n: "gemm2_kernel<1" in n or "gemm_kernel<1" in n),
-    ("dense gemm", lambda n: "gemm2_kernel<0" in n or "gemm_kernel<0" in n),
+    ("dense gemm", lambda n: "gemm2_kernel<0" in n or "gemm_kernel<0" in n or "gemm4_kernel" in n),
     ("gn_partial", lambda n: "gn_partial" in n), ("gn_apply", lambda n: "gn_apply" in n),
     ("gn_finalize", lambda n: "gn_finalize" in n), ("attn_d512", lambda n: "attn_d512" in n),
     ("window_attn", lambda n: "flash_attn" in n), ("im2col3d", lambda n: "im2col" in n),
