@@ -263,10 +263,49 @@ class NaDiTHip:
             y2 = y1  # unused downstream
         return x2, y2
 
+    GRAPH_MAX_TOKENS = 32768   # below this the ~450 launches of a forward pass cost more than their kernels
+
     @torch.no_grad()
     def one_step(self, noise: torch.Tensor, latent: torch.Tensor, txt: torch.Tensor, taps=None) -> torch.Tensor:
         """x0 = noise - NaDiT(cat[noise, latent, 1])  [ref: src/core/infer.py:54-78,294-374;
-        common/diffusion/schedules/base.py:108-110].  noise, latent: bf16 [T,H,W,16]; txt bf16 [Lt, txt_in_dim]."""
+        common/diffusion/schedules/base.py:108-110].  noise, latent: bf16 [T,H,W,16]; txt bf16 [Lt, txt_in_dim].
+        Small grids replay a captured hipGraph of the whole forward pass (SVR2_DIT_GRAPH=0 disables, =1 forces):
+        the pass is a fixed sequence of launches for a given grid, with no host synchronisation inside."""
+        mode = os.environ.get("SVR2_DIT_GRAPH", "auto")
+        tokens = noise.shape[0] * noise.shape[1] * noise.shape[2] // 4
+        if taps is None and mode != "0" and (mode == "1" or tokens <= self.GRAPH_MAX_TOKENS):
+            return self._one_step_graph(noise, latent, txt)
+        return self._one_step_eager(noise, latent, txt, taps)
+
+    @torch.no_grad()
+    def _one_step_graph(self, noise: torch.Tensor, latent: torch.Tensor, txt: torch.Tensor) -> torch.Tensor:
+        txt = txt.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        key = (tuple(noise.shape), tuple(txt.shape))
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if key not in self._graphs:
+            s_noise, s_latent, s_txt = noise.clone(), latent.clone(), txt.clone()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):        # warm-up: plans, rope tables, kernel attributes, allocator
+                for _ in range(2):
+                    self._one_step_eager(s_noise, s_latent, s_txt, None)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._one_step_eager(s_noise, s_latent, s_txt, None)
+            if len(self._graphs) >= 4:           # every graph keeps its intermediates in a private pool: bound the cache
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = (g, s_noise, s_latent, s_txt, out)
+        g, s_noise, s_latent, s_txt, out = self._graphs[key]
+        s_noise.copy_(noise)
+        s_latent.copy_(latent)
+        s_txt.copy_(txt)
+        g.replay()
+        return out.clone()
+
+    @torch.no_grad()
+    def _one_step_eager(self, noise: torch.Tensor, latent: torch.Tensor, txt: torch.Tensor, taps=None) -> torch.Tensor:
         cfg = self.cfg
         T, Hh, Ww, Cc = noise.shape
         if Hh % 2 or Ww % 2:

@@ -339,6 +339,38 @@ def test_gemm_gelu(pkg, gpu):
     assert_close(out, F.gelu(a @ w.T + b, approximate="tanh"), "gemm gelu")
 
 
+def test_dit_graph_replay_equals_eager(pkg, gpu, monkeypatch):
+    """Small grids replay a captured hipGraph of the forward pass: same bits as the eager launches, for fresh inputs too."""
+    import time
+    from seedvr2_ref import dit as odit
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=4, mm_layers=2, txt_in_dim=64, mlp_multiple_of=64)
+    dcfg = odit.DiTConfig(**kw)
+    dp = {k: v.to(torch.bfloat16).float() for k, v in odit.synthetic_params(dcfg, 5).items()}
+    model = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(**kw), dp, gpu)
+    g = torch.Generator().manual_seed(6)
+    txt = torch.randn(58, 64, generator=g).to(torch.bfloat16).to(gpu)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SVR2_DIT_GRAPH", mode)
+        res = []
+        for seed in (1, 2, 3):
+            gg = torch.Generator().manual_seed(seed)
+            noise = torch.randn(3, 8, 12, 16, generator=gg).to(torch.bfloat16).to(gpu)
+            lat = torch.randn(3, 8, 12, 16, generator=gg).to(torch.bfloat16).to(gpu)
+            res.append(model.one_step(noise, lat, txt).clone())
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            model.one_step(noise, lat, txt)
+        torch.cuda.synchronize()
+        outs[mode] = (res, (time.time() - t0) / 10)
+    for a, b in zip(outs["0"][0], outs["1"][0]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs["1"][0][0], outs["1"][0][1])
+    print(f"DiT forward (4 layers, 72 tokens): eager {outs['0'][1]*1e3:.2f} ms, graph replay {outs['1'][1]*1e3:.2f} ms")
+    assert len(model._graphs) == 1
+
+
 @pytest.mark.parametrize("grid_thw", [(2, 16, 24), (3, 20, 36)])
 def test_dit_7b_variant_vs_oracle(pkg, gpu, grid_thw):
     """NaDiT-7B deltas: GELU MLP with biases, separate vid/txt weights in every layer, video-only 'pixel'
