@@ -292,7 +292,8 @@ class NaDiTHip:
                     self._one_step_eager(s_noise, s_latent, s_txt, None)
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: the frame reader / writer threads may allocate pinned memory while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self._one_step_eager(s_noise, s_latent, s_txt, None)
             if len(self._graphs) >= 4:           # every graph keeps its intermediates in a private pool: bound the cache
                 self._graphs.pop(next(iter(self._graphs)))
