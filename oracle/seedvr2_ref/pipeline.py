@@ -142,9 +142,9 @@ def blur_timestep(latent_shape, scale: float, dtype=torch.bfloat16, T: float = 1
 def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, resolution: int, batch_size: int = 5,
              temporal_overlap: int = 0, seed: int = 42, dtype=torch.float32, uniform_batch_size: bool = False,
              taps: dict | None = None, color_correction: str = "none", input_noise_scale: float = 0.0,
-             latent_noise_scale: float = 0.0) -> torch.Tensor:
+             latent_noise_scale: float = 0.0, rope_mode: str = "3b") -> torch.Tensor:
     """frames [N,H,W,3] float in [0,1] -> [N,true_h,true_w,3] in [0,1] (dtype bf16 storage between phases,
-    model arithmetic in `dtype`)."""
+    model arithmetic in `dtype`).  rope_mode "3b" | "7b" | "none" selects the DiT's rotary embedding."""
     N, H, W, _ = frames.shape
     rh, rw, th, tw, ph, pw = target_dims(H, W, resolution)
     ranges, overlap = batch_ranges(N, batch_size, temporal_overlap)
@@ -168,7 +168,7 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
         noise = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16)
         second = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16)   # always drawn (:679)
         cond_latent = latent_blur(latent, noise, second, latent_noise_scale)
-        x0 = _dit.one_step_sr(dit_p, dit_cfg, cond_latent.to(dtype), noise.to(dtype), text_pos.to(dtype), dtype)
+        x0 = _dit.one_step_sr(dit_p, dit_cfg, cond_latent.to(dtype), noise.to(dtype), text_pos.to(dtype), dtype, rope_mode)
         x0 = x0.to(torch.bfloat16)
         dec = _vae.decode(vae_p, x0.to(dtype), vae_cfg, dtype).to(torch.bfloat16)   # [3,T,Hp,Wp]
         if taps is not None and bi == 0:

@@ -1,0 +1,153 @@
+"""Full-WIDTH parity: the real architectures (NaDiT-3B: 32 layers x 2560, 20 heads, K = 6912 MLP GEMMs;
+NaDiT-7B: 36 layers x 3072, 24 heads, K = 12288; VAE 128/256/512/512) on BASELINE configs[0]
+([1,256,256,3] -> 512x512, seed 42, color_correction none), HIP path vs the fp32 AND the bf16 oracle
+on the same synthetic weights, plus a full-width NaDiT (separate / shared / last layer) at configs[1]'s
+DiT grid (3,68,120).
+
+Reference path being matched: src/core/generation_phases.py:342-521,650-753,904-1026,
+src/core/infer.py:117-257, src/models/dit_3b/nadit.py:190-248 (dit_7b/nadit.py for the 7B).
+
+Tolerances (floating point; stated here): the reference's own CPU path computes in bf16 op by op
+(optimization/compatibility.py:207-221) and therefore deviates from exact arithmetic by e_bf16 =
+|oracle_bf16 - oracle_fp32|.  The HIP path (bf16 storage, fp32 accumulation) must satisfy, per stage,
+    rel_rms(hip, fp32) <= 2 * rel_rms(bf16 oracle, fp32) + 2e-3
+and on the decoded RGB in [0,1]
+    PSNR(hip, fp32) >= PSNR(bf16 oracle, fp32) - 3 dB   and   PSNR(hip, bf16 oracle) >= PSNR(fp32, bf16 oracle) - 3 dB
+i.e. the HIP result is as close to either flavour of the reference as they are to each other.
+The measured numbers are written to gpurun_out/fullwidth_parity.json (BASELINE.md section 4 / DESIGN section 6).
+"""
+
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from tests_support import psnr
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def _record(name, row):
+    path = os.path.join(ROOT, "gpurun_out", "fullwidth_parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        with open(path) as fh:
+            data = json.load(fh)
+    data[name] = row
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1)
+
+
+def _lr_image(seed=1234):
+    """SURVEY 8d synthetic input: smooth seeded content, uint8-quantised then /255 like the CLI."""
+    g = torch.Generator().manual_seed(seed)
+    low = 0.5 + 0.2 * torch.randn(1, 3, 16, 16, generator=g)
+    x = torch.nn.functional.interpolate(low, size=(256, 256), mode="bicubic", align_corners=False).clamp(0, 1)
+    return ((x * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
+
+
+def _cpu_params(sd):
+    """The device state dict (bf16 values) as CPU tensors for the oracle (it casts per use)."""
+    return {k: v.detach().cpu() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("model", ["3b", "7b"])
+def test_cfg1_end_to_end_full_width(pkg, gpu, model):
+    from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t_all = time.time()
+    dcfg_h = pkg.dit.CFG_3B if model == "3b" else pkg.dit.CFG_7B
+    dcfg_o = odit.CFG_3B if model == "3b" else odit.CFG_7B
+    rope = "3b" if model == "3b" else "7b"
+    vcfg_h, vcfg_o = pkg.vae.VAEConfig(), ovae.VAEConfig()
+    assert tuple(vcfg_h.block_out_channels) == (128, 256, 512, 512) and dcfg_h.num_layers in (32, 36)
+    vsd = pkg.vae.synthetic_state_dict(vcfg_h, gpu, seed=1)
+    dsd = pkg.dit.synthetic_state_dict(dcfg_h, gpu, seed=2)
+    vae = pkg.vae.VideoVAEHip(vcfg_h, vsd, gpu)
+    dit = pkg.dit.NaDiTHip(dcfg_h, dsd, gpu)
+    vp, dp = _cpu_params(vsd), _cpu_params(dsd)
+    del vsd, dsd
+    txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).float()
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    lr = _lr_image()
+
+    # HIP path: the product's generate() for the RGB, and the same stages one by one for the taps
+    got = pipe.generate(lr, resolution=512, batch_size=1, temporal_overlap=0, seed=42, color_correction="none").float().cpu()
+    x = pipe.transform(lr.to(gpu).to(torch.bfloat16), 512)
+    lat = vae.encode(x)
+    noise = pipe.make_noise(lat.shape, 42)
+    x0 = dit.one_step(noise.to(gpu), lat, pipe.text_pos)
+    torch.cuda.synchronize()
+    hip_taps = {"latent": lat.float().cpu(), "x0": x0.float().cpu()}
+    assert got.shape == (1, 512, 512, 3) and tuple(hip_taps["latent"].shape) == (1, 64, 64, 16)
+
+    refs, taps = {}, {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        t0 = time.time()
+        taps[name] = {}
+        refs[name] = opipe.generate(lr, vp, vcfg_o, dp, dcfg_o, txt, 512, 1, 0, 42, dt, taps=taps[name],
+                                    rope_mode=rope).float()
+        print(f"[{model}] oracle {name}: {time.time() - t0:.1f}s on {torch.get_num_threads()} threads")
+
+    row = {"model": model, "input": "[1,256,256,3] -> 512x512, seed 42, color_correction none"}
+    for stage in ("latent", "x0"):
+        e_hip = _rel(hip_taps[stage], taps["fp32"][stage])
+        e_b16 = _rel(taps["bf16"][stage], taps["fp32"][stage])
+        row[f"{stage}_rel_rms_hip_vs_fp32"] = e_hip
+        row[f"{stage}_rel_rms_bf16oracle_vs_fp32"] = e_b16
+        row[f"{stage}_rel_rms_hip_vs_bf16oracle"] = _rel(hip_taps[stage], taps["bf16"][stage])
+        print(f"[{model}] {stage}: rel-rms hip vs fp32 {e_hip:.3e}; bf16 oracle vs fp32 {e_b16:.3e}")
+        assert torch.isfinite(hip_taps[stage]).all()
+        assert e_hip <= 2.0 * e_b16 + 2e-3, (stage, e_hip, e_b16)
+    p_hip32, p_b16 = psnr(got, refs["fp32"]), psnr(refs["bf16"], refs["fp32"])
+    p_hip16 = psnr(got, refs["bf16"])
+    row.update(psnr_hip_vs_fp32=p_hip32, psnr_bf16oracle_vs_fp32=p_b16, psnr_hip_vs_bf16oracle=p_hip16,
+               maxabs_hip_vs_fp32=float((got - refs["fp32"]).abs().max()),
+               maxabs_bf16oracle_vs_fp32=float((refs["bf16"] - refs["fp32"]).abs().max()),
+               maxabs_hip_vs_bf16oracle=float((got - refs["bf16"]).abs().max()),
+               seconds=time.time() - t_all, cpu_threads=torch.get_num_threads())
+    print(f"[{model}] decoded RGB: PSNR hip vs fp32 {p_hip32:.2f} dB (bf16 oracle vs fp32 {p_b16:.2f} dB), hip vs bf16 oracle "
+          f"{p_hip16:.2f} dB; max|d| {row['maxabs_hip_vs_fp32']:.4f} (bf16 oracle {row['maxabs_bf16oracle_vs_fp32']:.4f})")
+    _record(f"cfg1_{model}", row)
+    assert p_hip32 >= p_b16 - 3.0 and p_hip16 >= p_b16 - 3.0 and p_hip32 > 30.0
+
+
+def test_dit_full_width_cfg2_grid(pkg, gpu):
+    """NaDiT at full 3B width (2560, 20 heads, hidden 6912) with a separate-weights layer, a shared layer and the
+    vid-only last layer on configs[1]'s DiT grid (3,68,120): 24 480 tokens, 75 regular / 90 shifted windows."""
+    from seedvr2_ref import dit as odit
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    kw = dict(num_layers=3, mm_layers=1)
+    hcfg, ocfg = pkg.dit.DiTConfig(**kw), odit.DiTConfig(**kw)
+    sd = pkg.dit.synthetic_state_dict(hcfg, gpu, seed=4)
+    model = pkg.dit.NaDiTHip(hcfg, sd, gpu)
+    p = _cpu_params(sd)
+    del sd
+    g = torch.Generator().manual_seed(5)
+    T, H, W = 3, 136, 240
+    noise = torch.randn(T, H, W, 16, generator=g).to(torch.bfloat16)
+    latent = torch.randn(T, H, W, 16, generator=g).to(torch.bfloat16)
+    txt = (0.5 * torch.randn(58, 5120, generator=g)).to(torch.bfloat16)
+    got = model.one_step(noise.to(gpu), latent.to(gpu), txt.to(gpu)).float().cpu()
+    t0 = time.time()
+    ref32 = odit.one_step_sr(p, ocfg, latent.float(), noise.float(), txt.float(), torch.float32)
+    t1 = time.time()
+    ref16 = odit.one_step_sr(p, ocfg, latent, noise, txt, torch.bfloat16).float()
+    print(f"oracle fp32 {t1 - t0:.1f}s, bf16 {time.time() - t1:.1f}s")
+    e_hip, e_b16 = _rel(got, ref32), _rel(ref16, ref32)
+    print(f"NaDiT full width @ (3,68,120): rel-rms hip vs fp32 {e_hip:.3e}; bf16 oracle vs fp32 {e_b16:.3e}")
+    _record("dit_fullwidth_cfg2_grid", {"grid": [3, 68, 120], "layers": 3, "rel_rms_hip_vs_fp32": e_hip,
+                                        "rel_rms_bf16oracle_vs_fp32": e_b16, "rel_rms_hip_vs_bf16oracle": _rel(got, ref16),
+                                        "maxabs_over_rms_hip": float((got - ref32).abs().max() / ref32.pow(2).mean().sqrt())})
+    assert torch.isfinite(got).all()
+    assert e_hip <= 2.0 * e_b16 + 2e-3
