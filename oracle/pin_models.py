@@ -149,6 +149,7 @@ def build_reference_dit(model, overrides, seed):
     with open(os.path.join(REF, f"configs_{model}/main.yaml")) as fh:
         cfg = yaml.safe_load(fh)["dit"]["model"]
     cfg.pop("__object__")
+    cfg["norm_eps"] = float(cfg["norm_eps"])     # '1e-5' is a float for OmegaConf's resolver, a string for YAML 1.1
     cfg.update(overrides)
     n = cfg["num_layers"]
     cfg["txt_dim"] = cfg["vid_dim"]
@@ -247,6 +248,7 @@ def build_reference_dit_meta(model):
     with open(os.path.join(REF, f"configs_{model}/main.yaml")) as fh:
         cfg = yaml.safe_load(fh)["dit"]["model"]
     cfg.pop("__object__")
+    cfg["norm_eps"] = float(cfg["norm_eps"])
     n = cfg["num_layers"]
     cfg["txt_dim"], cfg["emb_dim"] = cfg["vid_dim"], 6 * cfg["vid_dim"]
     cfg["block_type"] = _expand(n, "mmdit_sr")
@@ -272,7 +274,8 @@ def _extract(path, names, ns):
 def pin_host_helpers(tensors, meta):
     print("G10b pad_video_temporal / blend_overlapping_frames / _apply_4n1_padding (taken from the syntax tree, run as they are)")
     from typing import Optional
-    ns = {"torch": torch, "Optional": Optional}
+    from src.optimization.performance import optimized_single_video_rearrange   # the reference's own helper
+    ns = {"torch": torch, "Optional": Optional, "optimized_single_video_rearrange": optimized_single_video_rearrange}
     _extract(os.path.join(REF, "src/core/generation_utils.py"), ("pad_video_temporal", "blend_overlapping_frames"), ns)
     _extract(os.path.join(REF, "src/core/generation_phases.py"), ("_apply_4n1_padding",), ns)
     pad, blend, pad4 = ns["pad_video_temporal"], ns["blend_overlapping_frames"], ns["_apply_4n1_padding"]
@@ -284,7 +287,7 @@ def pin_host_helpers(tensors, meta):
             mine = opipe.pad_video_temporal(v, count)[:, 0, 0, 0].long().tolist()
             assert ref == mine, (t, count, ref, mine)
             table[f"{t}|{count}"] = ref
-        ref4 = pad4(v, None)[:, 0, 0, 0].long().tolist()
+        ref4 = pad4(v)[:, 0, 0, 0].long().tolist()
         assert ref4 == table[f"{t}|0"]
         # CTHW flavour (temporal_dim=1), which encode_all_batches never uses for padding but prepend does
         vc = v.permute(1, 0, 2, 3)
@@ -304,6 +307,63 @@ def pin_host_helpers(tensors, meta):
             tensors[f"G10b.blend.{ov}.{tag}.out"] = ref
 
 
+# ================================================================================================ G16h / G17h
+def _fingerprint(params):
+    """Order-independent checksum of a seeded parameter set (the fixtures store it instead of the weights)."""
+    return float(sum(v.double().abs().sum().item() * (1 + (i % 7)) for i, (k, v) in enumerate(sorted(params.items()))))
+
+
+def pin_hip_sized(tensors, dit_tensors, meta):
+    """Reference models at sizes the HIP kernels accept (head_dim 128; VAE widths 64/128/512/512), weights =
+    the oracle's seeded synthetic parameters rounded to bf16 (regenerated by the tests from the seed: only inputs
+    and the REFERENCE's outputs are stored).  The GPU tests compare the HIP path with these outputs directly."""
+    print("G16h / G17h reference outputs at HIP-compatible sizes (seeded weights, not stored)")
+    # ---- VAE
+    ch = (64, 128, 512, 512)
+    vae, cfg, main = build_reference_vae(ch, 32, seed=51)
+    ocfg = ovae.VAEConfig(block_out_channels=ch)
+    p = {k: v.to(torch.bfloat16).float() for k, v in ovae.synthetic_params(ocfg, 52).items()}
+    missing, unexpected = vae.load_state_dict(p, strict=True), None
+    g = torch.Generator().manual_seed(53)
+    x = (torch.rand(1, 3, 9, 32, 48, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    with torch.no_grad():
+        enc = vae.encode(x)
+        z = enc.latent
+        zq = (z * ocfg.scaling_factor).to(torch.bfloat16).float()          # the latent the runner hands on (infer.py:176)
+        dec = vae.decode(zq / ocfg.scaling_factor).sample
+        check("G16h oracle encoder == reference", ovae.encoder(p, x[0], ocfg)[:16], z[0], 5e-5)
+        check("G16h oracle decoder == reference", ovae.decoder(p, (zq / ocfg.scaling_factor)[0], ocfg), dec[0], 1e-4)
+    tensors.update({"G16h.x": x[0].clone(), "G16h.z": z[0].clone(), "G16h.latent_in": zq[0].clone(), "G16h.dec": dec[0].clone()})
+    meta["G16h"] = {"block_out_channels": list(ch), "param_seed": 52, "fingerprint": _fingerprint(p)}
+    # ---- NaDiT (3B flavour and 7B flavour), head_dim 128
+    for model, over, thw, rope, okw in (
+        ("3b", dict(vid_dim=256, heads=2, head_dim=128, rope_dim=128, num_layers=4, mm_layers=2, txt_in_dim=64), (2, 16, 24), "3b",
+         dict(vid_dim=256, heads=2, head_dim=128, num_layers=4, mm_layers=2, txt_in_dim=64)),
+        ("7b", dict(vid_dim=256, heads=2, head_dim=128, num_layers=3, txt_in_dim=64), (3, 20, 36), "7b",
+         dict(vid_dim=256, heads=2, head_dim=128, num_layers=3, mm_layers=3, txt_in_dim=64, mlp_type="normal", out_norm=False,
+              last_vid_only=False)),
+    ):
+        net, cfg = build_reference_dit(model, over, seed=54)
+        ocfg = odit.DiTConfig(**okw)
+        p = {k: v.to(torch.bfloat16).float() for k, v in odit.synthetic_params(ocfg, 55).items()}
+        res = net.load_state_dict(p, strict=False)
+        assert not res.unexpected_keys and all("rope" in k for k in res.missing_keys), res
+        T, H, W = thw
+        g = torch.Generator().manual_seed(56)
+        noise = torch.randn(T, H, W, 16, generator=g).to(torch.bfloat16).float()
+        latent = torch.randn(T, H, W, 16, generator=g).to(torch.bfloat16).float()
+        txt = torch.randn(58, 64, generator=g).to(torch.bfloat16).float()
+        vid = torch.cat((noise, latent, torch.ones(T, H, W, 1)), dim=-1).reshape(-1, 33)     # infer.py:54-78 condition
+        with torch.no_grad():
+            ref = net(vid=vid, txt=txt, vid_shape=torch.tensor([[T, H, W]]), txt_shape=torch.tensor([[58]]),
+                      timestep=torch.tensor([1000.0])).vid_sample
+            check(f"G17h[{model}] oracle forward == reference", odit.forward(p, ocfg, vid, txt, (T, H, W), 1000.0, torch.float32, rope),
+                  ref, 1e-4)
+        dit_tensors.update({f"G17h.{model}.noise": noise, f"G17h.{model}.latent": latent, f"G17h.{model}.txt": txt,
+                        f"G17h.{model}.pred": ref.clone()})
+        meta[f"G17h.{model}"] = {"cfg": okw, "param_seed": 55, "fingerprint": _fingerprint(p), "latent_thw": list(thw), "rope": rope}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_standins.install()
@@ -313,9 +373,10 @@ def main():
     pin_vae(vt, meta)
     pin_dit(dt_, meta)
     pin_dit_keys_fullsize(meta)
+    pin_hip_sized(ht, dt_, meta)
     vt.update(ht)
-    save_file({k: v.contiguous() for k, v in vt.items()}, os.path.join(GOLD, "vae_model_pins.safetensors"))
-    save_file({k: v.contiguous() for k, v in dt_.items()}, os.path.join(GOLD, "dit_model_pins.safetensors"))
+    save_file({k: v.contiguous().clone() for k, v in vt.items()}, os.path.join(GOLD, "vae_model_pins.safetensors"))
+    save_file({k: v.contiguous().clone() for k, v in dt_.items()}, os.path.join(GOLD, "dit_model_pins.safetensors"))
     with open(os.path.join(GOLD, "model_pins.json"), "w") as fh:
         json.dump(meta, fh)
     print("model-level golden vectors written to", GOLD)
