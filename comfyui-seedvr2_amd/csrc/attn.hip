@@ -212,13 +212,7 @@ __global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(co
 template <int HD, int KT>
 int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int LDS = 4 * KT * HD * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<HD, KT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "flash_attn: cannot reserve %d bytes of LDS", LDS);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS((flash_attn_kernel<HD, KT>), LDS, "flash_attn");
     hipLaunchKernelGGL((flash_attn_kernel<HD, KT>), grid, dim3(NTH), LDS, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;

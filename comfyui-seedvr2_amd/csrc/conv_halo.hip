@@ -431,12 +431,7 @@ int launch_halo(KArgs a, hipStream_t s) {
     const void* fn;
     if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN>;
     else fn = (const void*)conv_halo_kernel<PW, BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", G::LDS);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS(fn, G::LDS, "conv_halo");
     a.cg.patch = 2;
     a.cg.tiles_x = (a.cg.Wo + PW - 1) / PW;
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
@@ -456,8 +451,7 @@ int conv_halo_launch(KArgs a, hipStream_t s) {
     // SVR2_HALO_WR: bit 0 = W through registers (conv_halo_wr_kernel) for the 256-channel geometry, bit 1 = for the
     // 128-channel geometry (default 3; 0 = both through LDS).  Measured, same box (profiles/r01_kernel_bench_halo_wr.log):
     // 1438 -> 1603, 1510 -> 1656 TFLOP/s (256-channel blocks), 1393 -> 1448 (128-channel blocks).
-    const char* e = getenv("SVR2_HALO_WR");
-    const int wr = e ? atoi(e) : 3;
+    const int wr = svr2::opt(svr2::OPT_HALO_WR, 3);
     // 256-channel column blocks read two 128-row W tile columns: only when Cout is a multiple of 256
     if (a.N % 256 == 0) return (wr & 1) ? launch_halo<16, 256, true>(a, s) : launch_halo<16, 256, false>(a, s);
     // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile

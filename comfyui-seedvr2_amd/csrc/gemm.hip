@@ -14,6 +14,7 @@
 #include "gemm_args.h"
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -284,17 +285,11 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
 template <int AMODE, int EPI, int BM>
 int launch_bm(KArgs a, hipStream_t s) {
     using G = Geo<BM>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AMODE, EPI, BM>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "gemm: cannot reserve %d bytes of LDS", G::LDS_BYTES);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS((gemm_kernel<AMODE, EPI, BM>), G::LDS_BYTES, "gemm");
     a.nbm = (a.M + BM - 1) / BM;
     a.nbn = (a.N + BN - 1) / BN;
     if (AMODE == A_CONV) {
-        a.cg.patch = (a.cg.Ho % (BM / 16) == 0 && a.cg.Wo % 16 == 0 && !getenv("SVR2_CONV_LINEAR_TILES")) ? 1 : 0;
+        a.cg.patch = (a.cg.Ho % (BM / 16) == 0 && a.cg.Wo % 16 == 0 && !svr2::opt(svr2::OPT_CONV_LINEAR_TILES, 0)) ? 1 : 0;
         a.cg.tiles_x = a.cg.Wo / 16;
         a.cg.tiles_y = a.cg.Ho / (BM / 16);
     }
@@ -303,14 +298,7 @@ int launch_bm(KArgs a, hipStream_t s) {
     return SVR2_OK;
 }
 
-inline int g_force_bm() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SVR2_GEMM_BM");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+inline int g_force_bm() { return svr2::opt(svr2::OPT_GEMM_BM, 0); }
 template <int AMODE, int EPI>
 int launch(const KArgs& a, hipStream_t s) {
     // measured on MI355X (profiles/r01_kernel_bench_*.log): two 128-row workgroups per CU beat one 256-row,
@@ -318,8 +306,7 @@ int launch(const KArgs& a, hipStream_t s) {
     // the other geometry for A/B runs.
     // Large problems go to the second-generation kernel (gemm2.hip: 256-row tiles, 128x64 per wave, BK 32,
     // 3-deep ring); SVR2_GEMM_V=1 keeps everything on this kernel for A/B runs.
-    const char* ev = getenv("SVR2_GEMM_V");     // read per call: tests switch kernels with it
-    const int ver = ev ? atoi(ev) : 2;
+    const int ver = svr2::opt(svr2::OPT_GEMM_V, 2);         // tests switch kernels with svr2_set_option
     const long long tiles2 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     // measured (profiles/r01_*): the 256x256x64 geometry wins by 16-20 % wherever N is a multiple of 256; for
     // N = 128 the 256x128x32 geometry is +3 % on 128-channel inputs and -18 % on 256-channel inputs.
@@ -330,8 +317,7 @@ int launch(const KArgs& a, hipStream_t s) {
     // group more than a LOAD phase has - measured 535 vs 850 TFLOP/s)
     if (AMODE == A_DENSE && a.N % 256 == 0 && a.K % 64 == 0 &&
         ((a.K >= 1024 && tiles2 >= 384 && !a.a_rows) || (ver == 3 && a.K >= 128))) {
-        const char* e4 = getenv("SVR2_GEMM4");
-        if (!e4 || atoi(e4) != 0) return gemm4_launch(EPI, a, s);
+        if (svr2::opt(svr2::OPT_GEMM4, 1) != 0) return gemm4_launch(EPI, a, s);
     }
     const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.cg.Cin <= 128 && a.N == 128);
     if (((ver == 2 && tiles2 >= 384 && v2_shape) || ver == 3) && a.K % 32 == 0)
@@ -341,6 +327,45 @@ int launch(const KArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- tuning switches and per-device bookkeeping (common.h)
+namespace svr2 {
+static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
+                                                 "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V"};
+static const int kUnset = INT32_MIN;
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
+
+int opt(Opt o, int dflt) {
+    int v = g_opt[o].load(std::memory_order_relaxed);
+    if (v == kUnset) {                         // first use: the environment decides, once
+        const char* e = getenv(kOptNames[o]);
+        v = e ? atoi(e) : kDefault;
+        g_opt[o].store(v, std::memory_order_relaxed);
+    }
+    return v == kDefault ? dflt : v;
+}
+
+bool first_use_on_this_device(unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: set the attribute again
+    const unsigned long long bit = 1ull << dev;
+    if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return false;
+    __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+    return true;
+}
+}  // namespace svr2
+
+extern "C" int svr2_set_option(const char* name, int value, int unset) {
+    SVR2_CHECK(name, SVR2_E_ARG, "svr2_set_option: null name");
+    for (int i = 0; i < svr2::OPT_COUNT; ++i)
+        if (!strcmp(name, svr2::kOptNames[i])) {
+            svr2::g_opt[i].store(unset ? svr2::kDefault : value, std::memory_order_relaxed);
+            return SVR2_OK;
+        }
+    svr2_set_error("svr2_set_option: unknown option '%s'", name);
+    return SVR2_E_ARG;
+}
 
 static thread_local char g_err[512] = "";
 void svr2_set_error(const char* fmt, ...) {

@@ -227,13 +227,7 @@ __global__ __launch_bounds__(Geo2<BN>::NT, 2) void gemm2_kernel(const KArgs a) {
 template <int AMODE, int EPI, int BN>
 int launch2(KArgs a, hipStream_t s) {
     using G = Geo2<BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm2_kernel<AMODE, EPI, BN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "gemm2: cannot reserve %d bytes of LDS", G::LDS);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS((gemm2_kernel<AMODE, EPI, BN>), G::LDS, "gemm2");
     a.nbm = (a.M + BM2 - 1) / BM2;
     a.nbn = (a.N + BN - 1) / BN;
     if (AMODE == A_CONV) {
@@ -249,7 +243,7 @@ int launch2(KArgs a, hipStream_t s) {
 template <int AMODE, int EPI>
 int launch2_bn(const KArgs& a, hipStream_t s) {
     // 256-wide N tiles read W rows [n0, n0+256): only when N is a multiple of 256 (W is padded to 128 rows)
-    const bool wide = (a.N % 256 == 0) && !getenv("SVR2_GEMM2_NARROW");
+    const bool wide = (a.N % 256 == 0) && !svr2::opt(svr2::OPT_GEMM2_NARROW, 0);
     return wide ? launch2<AMODE, EPI, 256>(a, s) : launch2<AMODE, EPI, 128>(a, s);
 }
 

@@ -197,12 +197,7 @@ __global__ __launch_bounds__(NT4, 2) void gemm4_kernel(const KArgs a) {
 
 template <int EPI, bool GATHER>
 int launch4g(KArgs a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<EPI, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "gemm4: cannot reserve %d bytes of LDS", LDS4);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS((gemm4_kernel<EPI, GATHER>), LDS4, "gemm4");
     a.nbm = (a.M + BM4 - 1) / BM4;
     a.nbn = a.N / BN4;
     hipLaunchKernelGGL((gemm4_kernel<EPI, GATHER>), dim3(a.nbm * a.nbn), dim3(NT4), LDS4, s, a);

@@ -16,6 +16,9 @@ struct ResizeArgs {
 
 __device__ __forceinline__ float round_bf16(float v) { return round_bf16f(v); }
 
+// FINISH = true: resize -> bf16 -> clamp -> pad -> normalise (the model input); false: resize -> bf16 only (the first
+// of the two passes the reference runs when max_resolution caps the long edge, side_resize.py:61-73; Hp = Hout, Wp = Wout)
+template <bool FINISH>
 __global__ __launch_bounds__(256) void resize_pad_norm_kernel(const ResizeArgs a) {
     const long long total = (long long)a.T * a.Hp * a.Wp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -45,11 +48,11 @@ __global__ __launch_bounds__(256) void resize_pad_norm_kernel(const ResizeArgs a
             for (int c = 0; c < 3; ++c) {
                 // the reference rounds to bf16 after the resize, then clamps (generation_utils.py:80)
                 float v = round_bf16(acc[c]);
-                r[c] = fminf(fmaxf(v, 0.f), 1.f);
+                r[c] = FINISH ? fminf(fmaxf(v, 0.f), 1.f) : v;
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.out[i * 3 + c] = f2bf(round_bf16(r[c] - 0.5f) / 0.5f);
+        for (int c = 0; c < 3; ++c) a.out[i * 3 + c] = f2bf(FINISH ? round_bf16(r[c] - 0.5f) / 0.5f : r[c]);
     }
 }
 
@@ -126,8 +129,24 @@ extern "C" int svr2_resize_pad_normalize(const void* in, void* out, const float*
     a.in = (const bf16*)in; a.out = (bf16*)out; a.wy = wy; a.ymin = ymin; a.ycnt = ycnt; a.wx = wx; a.xmin = xmin;
     a.xcnt = xcnt; a.T = T; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Hp = Hp; a.Wp = Wp; a.KY = KY;
     a.KX = KX;
-    hipLaunchKernelGGL(resize_pad_norm_kernel, dim3(grid_1d((long long)T * Hp * Wp)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(resize_pad_norm_kernel<true>, dim3(grid_1d((long long)T * Hp * Wp)), dim3(256), 0, (hipStream_t)stream,
                        a);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
+extern "C" int svr2_resize_bicubic_aa(const void* in, void* out, const float* wy, const int32_t* ymin, const int32_t* ycnt,
+                                      const float* wx, const int32_t* xmin, const int32_t* xcnt, int32_t T, int32_t Hin,
+                                      int32_t Win, int32_t Hout, int32_t Wout, int32_t KY, int32_t KX, void* stream) {
+    SVR2_CHECK(in && out && wy && ymin && ycnt && wx && xmin && xcnt, SVR2_E_ARG, "svr2_resize_bicubic_aa: null pointer");
+    SVR2_CHECK(T > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && KY > 0 && KX > 0, SVR2_E_SHAPE,
+               "svr2_resize_bicubic_aa: bad sizes");
+    ResizeArgs a;
+    a.in = (const bf16*)in; a.out = (bf16*)out; a.wy = wy; a.ymin = ymin; a.ycnt = ycnt; a.wx = wx; a.xmin = xmin;
+    a.xcnt = xcnt; a.T = T; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Hp = Hout; a.Wp = Wout; a.KY = KY;
+    a.KX = KX;
+    hipLaunchKernelGGL(resize_pad_norm_kernel<false>, dim3(grid_1d((long long)T * Hout * Wout)), dim3(256), 0,
+                       (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

@@ -345,13 +345,7 @@ extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64
                SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
     SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
                "svr2_attn_d512: pointers must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_d512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           ATT5_LDS);
-        SVR2_CHECK(e == hipSuccess, SVR2_E_LAUNCH, "svr2_attn_d512: cannot reserve %d bytes of LDS", ATT5_LDS);
-        attr_set = true;
-    }
+    SVR2_SET_MAX_LDS(attn_d512_kernel, ATT5_LDS, "svr2_attn_d512");
     Attn5Args a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
     a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;

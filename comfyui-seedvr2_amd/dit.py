@@ -80,8 +80,12 @@ def _timestep_embedding(t: float, dim: int = 256) -> torch.Tensor:
 
 class NaDiTHip:
     def __init__(self, cfg: DiTConfig, params: Dict[str, torch.Tensor], device, timestep: float = 1000.0):
-        self.cfg = cfg
         self.device = torch.device(device)
+        self._init_on_device(cfg, params, timestep)
+
+    @hip.on_device
+    def _init_on_device(self, cfg: DiTConfig, params: Dict[str, torch.Tensor], timestep: float):
+        self.cfg = cfg
         self._plans = {}
         d = cfg.vid_dim
         dev = self.device
@@ -265,6 +269,7 @@ class NaDiTHip:
 
     GRAPH_MAX_TOKENS = 32768   # below this the ~450 launches of a forward pass cost more than their kernels
 
+    @hip.on_device
     @torch.no_grad()
     def one_step(self, noise: torch.Tensor, latent: torch.Tensor, txt: torch.Tensor, taps=None) -> torch.Tensor:
         """x0 = noise - NaDiT(cat[noise, latent, 1])  [ref: src/core/infer.py:54-78,294-374;

@@ -71,11 +71,11 @@ _INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_matc
 
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
+    "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_set_option", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
     "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_window_attn_scatter", "svr2_txt_mean", "svr2_patch_in",
     "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
     "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles",
-    "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_blend_overlap", "svr2_crop_to_unit",
+    "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_resize_bicubic_aa", "svr2_blend_overlap", "svr2_crop_to_unit",
     "svr2_wavelet_level", "svr2_wavelet_merge", "svr2_adain_ws_bytes", "svr2_adain", "svr2_rgb_to_lab",
     "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
     "svr2_rgb_to_hsv", "svr2_hue_sat_match_ws_bytes", "svr2_hue_sat_match", "svr2_hsv_to_rgb", "svr2_sat_blend",
@@ -109,11 +109,38 @@ def _check(rc: int, what: str):
 
 
 def _stream() -> C.c_void_p:
+    """The calling thread's current stream on its CURRENT device; `_p` rejects operands that live elsewhere, so a
+    kernel can never be enqueued on one GPU's stream with another GPU's pointers."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise HipError(f"operand lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "run the call under torch.cuda.device(tensor.device) (the pipeline / model entry points do)")
+    return C.c_void_p(t.data_ptr())
+
+
+def set_option(name: str, value: Optional[int]) -> None:
+    """A/B switch of the library (svr2_set_option): value None returns it to the built-in default."""
+    _check(lib().svr2_set_option(name.encode(), C.c_int(0 if value is None else int(value)), C.c_int(value is None)),
+           "svr2_set_option")
+
+
+def on_device(fn):
+    """Method decorator: run under torch.cuda.device(self.device), so launches use that device's stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def inner(self, *a, **k):
+        dev = torch.device(self.device)
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return inner
 
 
 def zero_page(device) -> torch.Tensor:
@@ -516,6 +543,24 @@ def resize_pad_normalize(frames: torch.Tensor, taps, hp: int, wp: int) -> torch.
                                            C.c_int32(T), C.c_int32(Hin), C.c_int32(Win), C.c_int32(Hout),
                                            C.c_int32(Wout), C.c_int32(hp), C.c_int32(wp), C.c_int32(KY), C.c_int32(KX),
                                            _stream()), "svr2_resize_pad_normalize")
+    return out
+
+
+def resize_bicubic_aa(frames: torch.Tensor, taps) -> torch.Tensor:
+    """frames bf16 [T,Hin,Win,3] -> bf16 [T,Hout,Wout,3]: the antialiased bicubic resize alone (bf16-rounded)."""
+    _bf16c(frames, "resize.frames")
+    if frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_contiguous():
+        raise HipError("resize: frames must be contiguous [T,H,W,3]")
+    T, Hin, Win, _ = frames.shape
+    wy, ymin, ycnt, wx, xmin, xcnt = taps
+    Hout, KY = wy.shape
+    Wout, KX = wx.shape
+    if int((ymin + ycnt).max()) > Hin or int((xmin + xcnt).max()) > Win or int(ycnt.max()) > KY or int(xcnt.max()) > KX:
+        raise HipError("resize: tap table reaches outside the input")
+    out = torch.empty(T, Hout, Wout, 3, dtype=torch.bfloat16, device=frames.device)
+    _check(lib().svr2_resize_bicubic_aa(_p(frames), _p(out), _p(wy), _p(ymin), _p(ycnt), _p(wx), _p(xmin), _p(xcnt),
+                                        C.c_int32(T), C.c_int32(Hin), C.c_int32(Win), C.c_int32(Hout), C.c_int32(Wout),
+                                        C.c_int32(KY), C.c_int32(KX), _stream()), "svr2_resize_bicubic_aa")
     return out
 
 

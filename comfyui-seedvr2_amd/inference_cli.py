@@ -8,18 +8,37 @@ video_io.py: .y4m, uncompressed/MJPEG .avi, image files, .npy
 containers through cv2 or an ffmpeg binary when present; the output container follows the extension of --output
 (--output_format mp4|png|y4m|avi|mjpeg|npy names it when --output has none; mjpeg = Motion-JPEG AVI encoded on the device).  --chunk_size streams the clip in chunks with
 --temporal_overlap raw context frames, like the reference.
-Multi-GPU: ``--cuda_device 0,1,...`` runs one process per GPU (torch.distributed / RCCL) with the
-reference's segment split and boundary blend (parallel.py)."""
+Multi-GPU: ``--cuda_device 0,1,...`` fans out by itself like the reference [ref: inference_cli.py:1048-1209]: the parent
+starts one fresh child process per listed GPU BEFORE touching any GPU (same CLI, RANK / WORLD_SIZE / LOCAL_RANK /
+MASTER_* set), the children form a torch.distributed group (RCCL over xGMI) and run the reference's segment split and
+boundary blend on the devices (parallel.py); a child that dies takes the others down instead of leaving them waiting.
+Launching the ranks with torchrun works too (WORLD_SIZE already set -> no fan-out)."""
 
 from __future__ import annotations
 
 import argparse
 import os
+import socket
+import subprocess
 import sys
 import time
+from typing import Callable, List, Optional
 
 import numpy as np
 import torch
+
+
+class Runtime:
+    """What `main` needs from the machine: the defaults are the product (one HIP device per rank, RCCL); tests substitute
+    a CPU flavour to drive the fan-out and the multi-rank control flow over gloo."""
+
+    def __init__(self, device_for: Optional[Callable[[str], str]] = None, set_device: Optional[Callable[[str], None]] = None,
+                 dist_backend: str = "nccl", child_cmd: Optional[List[str]] = None, poll_seconds: float = 0.2):
+        self.device_for = device_for or (lambda dev_id: f"cuda:{dev_id}")
+        self.set_device = set_device or (lambda dev: torch.cuda.set_device(torch.device(dev)))
+        self.dist_backend = dist_backend
+        self.child_cmd = child_cmd or [sys.executable, os.path.abspath(__file__)]
+        self.poll_seconds = poll_seconds
 
 
 def parse_arguments(argv=None):
@@ -74,8 +93,10 @@ def parse_arguments(argv=None):
         p.error("BlockSwap is unnecessary on 288 GB HBM: leave --blocks_to_swap 0")
     if a.tile_debug != "false":
         p.error("--tile_debug overlays are a debugging aid of the reference, not built here")
-    if a.batch_size % 4 != 1:
-        p.error("--batch_size must follow 4n+1")
+    if a.batch_size < 1:
+        p.error("--batch_size must be positive")
+    # any batch size is accepted: every batch is padded to 4n+1 with reversed tail frames like the reference
+    # [ref: src/core/generation_phases.py:109-124, 386-399]
     return a
 
 
@@ -193,8 +214,50 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
     return full.shape[0]
 
 
-def main(argv=None) -> int:
+def fan_out(devs: List[str], argv: List[str], rt: Runtime) -> int:
+    """The reference's multi-GPU entry [ref: inference_cli.py:1048-1209]: one fresh worker process per listed device,
+    started by a parent that has not touched (and never touches) a GPU.  Unlike the reference's workers, which return
+    their frames to the parent through host shared memory, the children exchange segment boundaries among themselves on
+    the devices and rank 0 writes the output.  Returns 0 when every child did; the first failing child takes the others
+    down (the reference's parent would wait forever on its queue)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for i in range(len(devs)):
+        env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(len(devs)), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(rt.child_cmd + list(argv), env=env))
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0].returncode
+            for p in procs:                      # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(rt.poll_seconds)
+    codes = [p.wait() for p in procs]
+    if failed or any(codes):
+        print(f"Error: multi-GPU worker exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def main(argv=None, runtime: Runtime = None) -> int:
+    rt = runtime or Runtime()
     a = parse_arguments(argv)
+    devs = [d for d in (a.cuda_device or "0").split(",") if d != ""]
+    if len(devs) > 1 and "WORLD_SIZE" not in os.environ:
+        # before the package (and with it the HIP library) is loaded: the parent never initialises a GPU
+        return fan_out(devs, list(sys.argv[1:] if argv is None else argv), rt)
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
     import __graft_entry__ as ge
@@ -203,24 +266,21 @@ def main(argv=None) -> int:
     t0 = time.time()
     dist = None
     try:
-        devs = [d for d in (a.cuda_device or "0").split(",") if d != ""]
         world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-        if len(devs) > 1 and world == 1:
-            raise SystemExit(f"multi-GPU: launch one process per GPU, `python -m torch.distributed.run --nproc-per-node "
-                             f"{len(devs)} --master-addr 127.0.0.1 inference_cli.py ...` (frame segments + one RCCL "
-                             "neighbour exchange, parallel.py / INTEGRATION.md)")
-        dev = f"cuda:{devs[local % len(devs)] if world > 1 else devs[0]}"
+        dev = rt.device_for(devs[local % len(devs)] if world > 1 else devs[0])
+        rt.set_device(dev)   # also for one rank: --cuda_device 3 must run on GPU 3's stream, not on GPU 0's
         if world > 1:   # the reference's multi-GPU mode: one segment per rank [ref: inference_cli.py:1048-1209]
             import torch.distributed as dist
-            torch.cuda.set_device(torch.device(dev))
-            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+            if rt.dist_backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+            else:
+                dist.init_process_group(backend=rt.dist_backend)
         dit_cfg, = pkg.nodes.SeedVR2LoadDiTModel.execute(model=a.dit_model, device=dev)
         vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(
             device=dev, encode_tiled=a.vae_encode_tiled, encode_tile_size=a.vae_encode_tile_size,
             encode_tile_overlap=a.vae_encode_tile_overlap, decode_tiled=a.vae_decode_tiled,
             decode_tile_size=a.vae_decode_tile_size, decode_tile_overlap=a.vae_decode_tile_overlap)
-        txt = pkg.weights.find_model_file("pos_emb.pt", a.model_dir) or os.path.join(here, "pos_emb.pt")
-        text_pos = torch.load(txt, weights_only=True)
+        text_pos = pkg.weights.load_text_embedding("pos_emb.pt", a.model_dir)
         itype = get_input_type(a.input, vio)
         nframes = 0
         if itype == "directory":   # batch mode: every media file on its own [ref: inference_cli.py:1525-1575]
@@ -232,7 +292,7 @@ def main(argv=None) -> int:
                     print(f"Processing file {i}/{len(files)}: {os.path.basename(fp)}", flush=True)
                 ftype = get_input_type(fp, vio)
                 fmt = a.output_format or ("mp4" if ftype == "video" else "png")
-                outp = generate_output_path(fp, fmt, a.output, input_type=ftype, from_directory=True)
+                outp = generate_output_path(fp, "avi" if fmt == "mjpeg" else fmt, a.output, input_type=ftype, from_directory=True)
                 keep, a.output_format = a.output_format, fmt
                 nframes += process_single_file(fp, a, pkg, dev, dit_cfg, vae_cfg, text_pos, outp, dist, rank, world)
                 a.output_format = keep

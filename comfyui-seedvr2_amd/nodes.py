@@ -138,9 +138,11 @@ def _out(value):
     return io.NodeOutput(value) if io is not None else (value,)
 
 
-def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor) -> _pipeline.SeedVR2Pipeline:
+def _build_pipeline(dit_cfg: dict, vae_cfg: dict, text_pos: torch.Tensor | None) -> _pipeline.SeedVR2Pipeline:
     key = (dit_cfg["model"], vae_cfg["model"], dit_cfg["device"])
     if key not in _PIPELINES:
+        if text_pos is None:   # inside ComfyUI execute() gets the schema inputs only [ref: generation_utils.py:528-533]
+            text_pos = _weights.load_text_embedding("pos_emb.pt")
         dev = torch.device(dit_cfg["device"])
         dpath = _weights.find_model_file(dit_cfg["model"])
         vpath = _weights.find_model_file(vae_cfg["model"])
@@ -219,8 +221,8 @@ class SeedVR2VideoUpscaler(_Base):
                                       f"(available: none, {', '.join(hip.COLOR_METHODS)})")
         if not (0.0 <= input_noise_scale <= 1.0 and 0.0 <= latent_noise_scale <= 1.0):
             raise ValueError("input_noise_scale and latent_noise_scale must lie in [0, 1]")
-        if batch_size % 4 != 1:
-            raise ValueError("batch_size must follow 4n+1")
+        if batch_size < 1:
+            raise ValueError("batch_size must be positive")   # any size: batches are padded to 4n+1 like the reference
         out = cls.run_device(image, dit, vae, seed, resolution, max_resolution, batch_size, uniform_batch_size,
                              temporal_overlap, prepend_frames, color_correction, text_pos=text_pos, pipeline=pipeline,
                              input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale)

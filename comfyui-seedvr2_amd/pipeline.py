@@ -37,6 +37,12 @@ def target_dims(h: int, w: int, resolution: int, max_resolution: int = 0) -> Tup
     return rh, rw, th, tw, ph, pw
 
 
+def uncapped_dims(h: int, w: int, resolution: int) -> Tuple[int, int]:
+    """(rh, rw) of the first resize (shortest edge -> resolution), before any `max_resolution` cap."""
+    rh, rw, *_ = target_dims(h, w, resolution, 0)
+    return rh, rw
+
+
 def _cubic(x: np.ndarray, a: float = -0.5) -> np.ndarray:
     x = np.abs(x).astype(np.float32)
     w1 = ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0
@@ -160,10 +166,17 @@ class SeedVR2Pipeline:
         return self._taps[key]
 
     # one batch, device resident ------------------------------------------------------------
+    @hip.on_device
     def transform(self, frames: torch.Tensor, resolution: int, max_resolution: int = 0) -> torch.Tensor:
         """frames bf16 [T,Hin,Win,3] in [0,1] -> bf16 [T,Hp,Wp,3] in [-1,1] (padding = -1)."""
         T, hin, win, _ = frames.shape
         rh, rw, _, _, ph, pw = target_dims(hin, win, resolution, max_resolution)
+        rh0, rw0 = uncapped_dims(hin, win, resolution)
+        if (rh0, rw0) != (rh, rw):
+            # the cap triggered: the reference resizes to the short-edge size first and then resizes THAT (bf16) image to
+            # the capped size [ref: data/image/transforms/side_resize.py:61-73] -- two cascaded antialiased passes
+            frames = hip.resize_bicubic_aa(frames, self._resize_taps(hin, win, rh0, rw0))
+            hin, win = rh0, rw0
         return hip.resize_pad_normalize(frames, self._resize_taps(hin, win, rh, rw), ph, pw)
 
     @staticmethod
@@ -196,6 +209,7 @@ class SeedVR2Pipeline:
         t = t * T
         return float(1 - (t / T)), float(t / T)
 
+    @hip.on_device
     def upscale_batch(self, lr_frames: torch.Tensor, resolution: int, seed: int, max_resolution: int = 0,
                       noise: Optional[torch.Tensor] = None, input_noise_scale: float = 0.0,
                       latent_noise_scale: float = 0.0, vae_generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -235,6 +249,7 @@ class SeedVR2Pipeline:
         return self.vae.decode(x0, **self.decode_tiling)
 
     # whole clip ----------------------------------------------------------------------------
+    @hip.on_device
     @torch.no_grad()
     def generate(self, frames: torch.Tensor, resolution: int, batch_size: int = 5, temporal_overlap: int = 0,
                  seed: int = 42, max_resolution: int = 0, uniform_batch_size: bool = False,

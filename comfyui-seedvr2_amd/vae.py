@@ -58,6 +58,12 @@ class _State:
 
 class VideoVAEHip:
     def __init__(self, cfg: VAEConfig, params: Dict[str, torch.Tensor], device):
+        self.device = torch.device(device)
+        self._init_on_device(cfg, params)
+
+    @hip.on_device
+    def _init_on_device(self, cfg: VAEConfig, params: Dict[str, torch.Tensor]):
+        device = self.device
         self.cfg = cfg
         self.device = torch.device(device)
         dev = self.device
@@ -233,6 +239,7 @@ class VideoVAEHip:
 
     # ------------------------------------------------------------------ public API
     @torch.no_grad()
+    @hip.on_device
     def encode(self, x: torch.Tensor, tiled: bool = False, tile_size: Tuple[int, int] = (512, 512),
                tile_overlap: Tuple[int, int] = (64, 64)) -> torch.Tensor:
         """x bf16 [T,H,W,3] in [-1,1], T = 4n+1, H,W multiples of 8 -> latent bf16 [T_l,h,w,16]
@@ -262,6 +269,7 @@ class VideoVAEHip:
         return (torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]).contiguous()
 
     @torch.no_grad()
+    @hip.on_device
     def decode(self, latent: torch.Tensor, tiled: bool = False, tile_size: Tuple[int, int] = (512, 512),
                tile_overlap: Tuple[int, int] = (64, 64)) -> torch.Tensor:
         """latent bf16 [T_l,h,w,16] -> bf16 [T,H,W,3], T = 4(T_l-1)+1  [ref: src/core/infer.py:192-257].

@@ -25,11 +25,36 @@ def find_model_file(name: str, model_dir: Optional[str] = None) -> Optional[str]
     return None
 
 
+def load_text_embedding(name: str = "pos_emb.pt", model_dir: Optional[str] = None) -> torch.Tensor:
+    """The positive prompt embedding the reference ships next to its scripts and loads from its script directory
+    [ref: src/core/generation_utils.py:528-533]: searched in `model_dir`, $SEEDVR2_MODEL_DIR, models/SEEDVR2, the current
+    directory, then this package's directory and its parent (a ComfyUI custom-node checkout keeps it at the repository
+    root).  Loaded with weights_only=True (a plain tensor; nothing from the file is executed)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    tried = []
+    for d in filter(None, (model_dir, os.environ.get("SEEDVR2_MODEL_DIR"), "models/SEEDVR2", ".", here, os.path.dirname(here))):
+        p = os.path.join(d, name)
+        tried.append(p)
+        if os.path.isfile(p):
+            t = torch.load(p, map_location="cpu", weights_only=True)
+            if isinstance(t, (list, tuple)):
+                t = t[0]
+            if not torch.is_tensor(t) or t.dim() not in (2, 3):
+                raise ValueError(f"{p}: expected a [tokens, dim] tensor")
+            return t.reshape(-1, t.shape[-1])
+    raise FileNotFoundError(f"{name} not found (copy the reference's {name} into one of: {', '.join(tried)})")
+
+
 def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
     if not path.endswith(".safetensors"):
         raise ValueError("only .safetensors checkpoints are loaded (no pickle execution)")
     from safetensors.torch import load_file
-    return load_file(path)
+    sd = load_file(path)
+    # fp8 (e4m3fn / e5m2) checkpoints: the reference keeps the fp8 storage and upcasts operands to the compute dtype around
+    # every call [ref: src/optimization/compatibility.py:261-265, 628-650]; every fp8 value is exactly representable in
+    # bf16, so converting once at load feeds the GEMMs the same weight values
+    fp8 = tuple(t for t in (getattr(torch, "float8_e4m3fn", None), getattr(torch, "float8_e5m2", None)) if t is not None)
+    return {k: (v.to(torch.bfloat16) if v.dtype in fp8 else v) for k, v in sd.items()}
 
 
 def config_for(dit_name: str):

@@ -14,7 +14,10 @@
  *     a thread-local message for the last failing call of the calling thread.
  *   - activations are bf16, row-major, channels-last; accumulation is fp32;
  *     per-channel vectors (bias, modulation, norm weights) are fp32.
- *   - no global mutable state; safe to call from several host threads / streams.
+ *   - safe to call from several host threads / streams and on several devices of one process (kernel
+ *     attributes are applied per device; launches go to the device `stream` belongs to, which must be the
+ *     calling thread's current device).  The only process-wide state is the table of tuning switches below,
+ *     resolved once (svr2_set_option, else the environment variable of the same name at first use).
  */
 #ifndef SEEDVR2_HIP_H
 #define SEEDVR2_HIP_H
@@ -40,6 +43,10 @@ int svr2_abi_version(void);
 const char* svr2_last_error(void);
 /* Checks that device `dev` is gfx950 and returns its CU count (>0) or an error code. */
 int svr2_device_check(int dev);
+/* Tuning switches for A/B measurements and tests (never needed in production): name is one of SVR2_HALO_WR,
+ * SVR2_GEMM_V, SVR2_GEMM4, SVR2_GEMM_BM, SVR2_GEMM2_NARROW, SVR2_CONV_LINEAR_TILES, SVR2_ATTN_V; unset != 0 returns
+ * the switch to its built-in default.  Switches never change results beyond fp32 summation order. */
+int svr2_set_option(const char* name, int value, int unset);
 
 /* ------------------------------------------------------------------ GEMM (+ fused epilogues)
  * C[M,N] = epilogue( A[M,K] * W[N,K]^T ),  bf16 in, fp32 accumulate, bf16 out.
@@ -241,6 +248,12 @@ int svr2_resize_pad_normalize(const void* in, void* out, const float* wy, const 
                               const int32_t* ycnt, const float* wx, const int32_t* xmin, const int32_t* xcnt,
                               int32_t T, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t Hp,
                               int32_t Wp, int32_t KY, int32_t KX, void* stream);
+/* The resize alone (result rounded to bf16, no clamp / pad / normalise): first pass of the reference's two-pass resize when
+ * `max_resolution` caps the long edge -- it resizes to the short-edge size, then resizes THAT bf16 image again
+ *   [ref: data/image/transforms/side_resize.py:61-73].  out bf16 [T,Hout,Wout,3]. */
+int svr2_resize_bicubic_aa(const void* in, void* out, const float* wy, const int32_t* ymin, const int32_t* ycnt,
+                           const float* wx, const int32_t* xmin, const int32_t* xcnt, int32_t T, int32_t Hin, int32_t Win,
+                           int32_t Hout, int32_t Wout, int32_t KY, int32_t KX, void* stream);
 /* out = prev_tail * w_prev[t] + cur_head * (1 - w_prev[t]) per frame t of the temporal overlap
  *   [ref: core/generation_utils.py:284-312; generation_phases.py:968-986]. */
 int svr2_blend_overlap(const void* prev_tail, const void* cur_head, void* out, const float* w_prev,

@@ -364,12 +364,62 @@ def pin_hip_sized(tensors, dit_tensors, meta):
         meta[f"G17h.{model}"] = {"cfg": okw, "param_seed": 55, "fingerprint": _fingerprint(p), "latent_thw": list(thw), "rope": rope}
 
 
+def pin_side_resize(tensors, meta):
+    """G10c: SideResize.__call__ (side_resize.py:36-75) and DivisiblePad (divisible_crop.py:43-80) taken from the syntax
+    tree and run as they are; `TVF.resize` is served by ATen's antialiased bicubic with torchvision's documented tensor
+    semantics (int size = short edge, long = int(size*long/short); non-float32 tensors are computed in fp32 and cast
+    back) -- torchvision is absent, so that one function is the unpinned part; the two-pass max_size logic is the reference's."""
+    print("G10c SideResize / DivisiblePad (classes taken from the syntax tree, TVF.resize served by ATen)")
+    import types
+    import torch.nn.functional as F
+    from typing import Union
+
+    def tvf_resize(img, size, interpolation=None, antialias=True):
+        h, w = img.shape[-2:]
+        if isinstance(size, int):
+            short, long_ = (w, h) if w <= h else (h, w)
+            new_short, new_long = size, int(size * long_ / short)
+            size = (new_long, new_short) if w <= h else (new_short, new_long)
+        out = F.interpolate(img.float(), size=tuple(size), mode="bicubic", align_corners=False, antialias=antialias)
+        return out.to(img.dtype)
+
+    class _Img:   # PIL.Image.Image stand-in (never instantiated)
+        pass
+
+    ns = {"torch": torch, "Union": Union, "Image": types.SimpleNamespace(Image=_Img),
+          "InterpolationMode": types.SimpleNamespace(BICUBIC="bicubic", BILINEAR="bilinear"),
+          "TVF": types.SimpleNamespace(resize=tvf_resize)}
+    for path, cls in (("src/data/image/transforms/side_resize.py", "SideResize"),
+                      ("src/data/image/transforms/divisible_crop.py", "DivisiblePad")):
+        with open(os.path.join(REF, path)) as fh:
+            tree = ast.parse(fh.read())
+        node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls]
+        assert len(node) == 1
+        exec(compile(ast.Module(body=node, type_ignores=[]), path, "exec"), ns)
+    g = torch.Generator().manual_seed(61)
+    cases = [((3, 27, 40), 54, 0), ((2, 27, 40), 54, 64), ((2, 40, 27), 54, 70), ((1, 30, 90), 64, 100), ((2, 36, 36), 50, 48)]
+    table = []
+    for i, ((t, h, w), res, cap) in enumerate(cases):
+        x = torch.rand(t, 3, h, w, generator=g).to(torch.bfloat16)
+        y = ns["SideResize"](size=res, max_size=cap)(x)
+        y = torch.clamp(y, 0.0, 1.0)
+        y = ns["DivisiblePad"]((16, 16))(y)
+        y = ((y - 0.5) / 0.5).permute(1, 0, 2, 3)          # Normalize(0.5, 0.5); t c h w -> c t h w (generation_utils.py:70-84)
+        mine = opipe.transform(x, res, cap)
+        check(f"G10c transform {h}x{w} -> {res} (max {cap})", mine.float(), y.float(), 0.0)
+        rh, rw = opipe.target_dims(h, w, res, cap)[:2]
+        table.append({"in": [t, h, w], "resolution": res, "max_resolution": cap, "resized": [rh, rw], "padded": list(y.shape[2:])})
+        tensors[f"G10c.{i}.x"], tensors[f"G10c.{i}.y"] = x, y.contiguous()
+    meta["G10c"] = table
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_standins.install()
     meta = {}
     vt, dt_, ht = {}, {}, {}
     pin_host_helpers(ht, meta)
+    pin_side_resize(ht, meta)
     pin_vae(vt, meta)
     pin_dit(dt_, meta)
     pin_dit_keys_fullsize(meta)

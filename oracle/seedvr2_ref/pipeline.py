@@ -36,8 +36,13 @@ def transform(frames_tchw_bf16: torch.Tensor, resolution: int, max_resolution: i
     Input bf16 [T,3,H,W]; every step rounds to bf16 like the reference's bf16 tensors."""
     T, C, H, W = frames_tchw_bf16.shape
     rh, rw, _, _, ph, pw = target_dims(H, W, resolution, max_resolution)
-    x = F.interpolate(frames_tchw_bf16.float(), size=(rh, rw), mode="bicubic", align_corners=False, antialias=True)
+    rh0, rw0 = target_dims(H, W, resolution, 0)[:2]
+    # SideResize (side_resize.py:61-73): resize to the short-edge size; if the long edge then exceeds max_size, resize the
+    # RESULT (a bf16 tensor; torchvision computes in fp32 and casts back) a second time to the capped size
+    x = F.interpolate(frames_tchw_bf16.float(), size=(rh0, rw0), mode="bicubic", align_corners=False, antialias=True)
     x = x.to(torch.bfloat16)
+    if (rh0, rw0) != (rh, rw):
+        x = F.interpolate(x.float(), size=(rh, rw), mode="bicubic", align_corners=False, antialias=True).to(torch.bfloat16)
     x = torch.clamp(x, 0.0, 1.0)
     x = F.pad(x, (0, pw - rw, 0, ph - rh), value=0.0)
     x = (x - 0.5) / 0.5

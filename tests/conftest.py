@@ -26,3 +26,17 @@ def gpu(pkg):
         pytest.skip("no GPU")
     pkg.hip.device_check(0)  # raises unless gfx950 + library present: no silent fallback
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def lib_option(pkg):
+    """Set a tuning switch of the library (svr2_set_option) for one test; restored to the default afterwards."""
+    touched = []
+
+    def set_(name, value):
+        pkg.hip.set_option(name, value)
+        touched.append(name)
+
+    yield set_
+    for name in touched:
+        pkg.hip.set_option(name, None)

@@ -170,3 +170,17 @@ def test_blend_overlapping_frames_vectors(pkg, vgold):
         a, b, out = (vgold[f"G10b.blend.{ov}.bf16.{k}"] for k in ("a", "b", "out"))
         wb = w.to(torch.bfloat16)
         assert torch.equal(a * wb + b * (1.0 - wb), out)
+
+
+def test_side_resize_two_pass_vectors(pkg, vgold, meta):
+    """SideResize + clamp + DivisiblePad + Normalize (side_resize.py:36-75 incl. the second resize when max_size caps
+    the long edge; divisible_crop.py:43-80) run as they are -> oracle.transform bit-exact; product geometry identical."""
+    from seedvr2_ref import pipeline as opipe
+    for i, c in enumerate(meta["G10c"]):
+        x, y = vgold[f"G10c.{i}.x"], vgold[f"G10c.{i}.y"]
+        assert torch.equal(opipe.transform(x, c["resolution"], c["max_resolution"]), y)
+        _, h, w = c["in"]
+        rh, rw, _, _, ph, pw = pkg.pipeline.target_dims(h, w, c["resolution"], c["max_resolution"])
+        assert [rh, rw] == c["resized"] and [ph, pw] == c["padded"]
+        capped = pkg.pipeline.uncapped_dims(h, w, c["resolution"]) != (rh, rw)
+        assert capped == (c["max_resolution"] > 0 and max(pkg.pipeline.uncapped_dims(h, w, c["resolution"])) > c["max_resolution"])

@@ -33,7 +33,7 @@ def _reference_concat(results, overlap):
     return out
 
 
-def _worker(rank, world, port, total, overlap, q):
+def _worker(rank, world, port, total, overlap, q, done):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -47,7 +47,10 @@ def _worker(rank, world, port, total, overlap, q):
         full = pkg.parallel.upscale_distributed(lambda seg: _fake_upscale(seg, rank), torch.arange(total), overlap, rank,
                                                 world, dist)
         if rank == 0:
-            q.put(full)
+            # plain bytes through the pipe (no shared-memory handle that could outlive this process), and rank 0 stays
+            # alive until the parent has the result
+            q.put(full.float().numpy())
+            done.wait(timeout=120)
     finally:
         dist.destroy_process_group()
 
@@ -58,15 +61,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,total,overlap", [(2, 23, 4), (2, 10, 0), (3, 17, 2), (2, 9, 3)])
+# (8, 512, 4) is BASELINE configs[4]'s partition: 8 ranks x 64 frames (+4 overlap), as 8 gloo processes
+@pytest.mark.parametrize("world,total,overlap", [(2, 23, 4), (2, 10, 0), (3, 17, 2), (2, 9, 3), (8, 512, 4)])
 def test_frame_sharding_matches_reference_semantics(pkg, world, total, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    done = ctx.Event()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, overlap, q, done)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = torch.from_numpy(q.get(timeout=240))
+    done.set()
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -36,17 +36,17 @@ def test_gemm_bias(pkg, gpu, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 384), (777, 2560, 2560), (256, 256, 6912), (513, 768, 192)])
-def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, monkeypatch):
+def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, lib_option):
     """gemm4.hip (ping-pong 256x256x64 kernel, five LDS sub-stages): forced onto small shapes with SVR2_GEMM_V=3."""
-    monkeypatch.setenv("SVR2_GEMM_V", "3")
+    lib_option("SVR2_GEMM_V", 3)
     hip = pkg.hip
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
     out = hip.gemm(dev_bf16(a, gpu), hip.pad_weight(w.to(gpu)), N, bias=b.to(gpu))
     assert_close(out, a @ w.T + b, f"gemm4 {M}x{N}x{K}")
 
 
-def test_gemm4_pingpong_epilogues(pkg, gpu, monkeypatch):
-    monkeypatch.setenv("SVR2_GEMM_V", "3")
+def test_gemm4_pingpong_epilogues(pkg, gpu, lib_option):
+    lib_option("SVR2_GEMM_V", 3)
     hip = pkg.hip
     M, N, K, S = 700, 256, 256, 900
     a, w = rnd(S, K, seed=4), rnd(N, K, seed=5, scale=1 / 16)
@@ -169,11 +169,11 @@ HALO_CASES = [
 
 @pytest.mark.parametrize("wr", ["0", "3"])
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_conv3d_halo_resident(pkg, gpu, case, wr, monkeypatch):
+def test_conv3d_halo_resident(pkg, gpu, case, wr, lib_option):
     """conv_halo.hip (halo kept in LDS, nine shifted reads, SVR2_WL_TILED_128x32 weights): both geometries, ragged
     edges, carry, resid; also against the tap-staged kernel on the same inputs."""
     hip = pkg.hip
-    monkeypatch.setenv("SVR2_HALO_WR", wr)   # W fragments through LDS (0) or straight into registers (1)
+    lib_option("SVR2_HALO_WR", int(wr))   # W fragments through LDS (0) or straight into registers (1)
     T, H, W, Cin, Cout, kt, with_carry, with_res = case
     k, s, npad, pad_hw = (kt, 3, 3), (1, 1, 1), kt - 1, (1, 1, 1, 1)
     x = rnd(T, H, W, Cin, seed=25)

@@ -77,3 +77,19 @@ def test_nadit_vs_reference_module_outputs(pkg, gpu, meta, model):
     print(f"NaDiT-{model} vs reference module (fp32): rel-rms hip {e_hip:.3e}, bf16 oracle {e_b16:.3e}; hip vs bf16 oracle {_rel(got, b16):.3e}")
     assert torch.isfinite(got).all()
     assert e_hip <= 2 * e_b16 + 2e-3
+
+
+def test_transform_vs_reference_side_resize(pkg, gpu, meta):
+    """P1 against the reference's own SideResize / DivisiblePad run as they are (G10c), including the two-pass resize
+    when max_resolution caps the long edge.  Same rounding points; the only freedom is the fp32 summation order inside
+    the resize: <= 1 bf16 ulp of the [-1,1] output on a few per cent of the pixels."""
+    gold = load_file(os.path.join(GOLD, "vae_model_pins.safetensors"))
+    pipe = pkg.pipeline.SeedVR2Pipeline(None, None, torch.zeros(1, 8), gpu)
+    for i, c in enumerate(meta["G10c"]):
+        x, y = gold[f"G10c.{i}.x"], gold[f"G10c.{i}.y"]                   # [T,3,H,W] bf16 -> [3,T,Hp,Wp] bf16
+        got = pipe.transform(x.permute(0, 2, 3, 1).contiguous().to(gpu), c["resolution"], c["max_resolution"]).float().cpu()
+        want = y.float().permute(1, 2, 3, 0)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        d = (got - want).abs()
+        assert d.max() <= 2 ** -7, (i, d.max())
+        assert (d > 0).float().mean() < 0.05, (i, (d > 0).float().mean())
