@@ -31,10 +31,15 @@ struct AttnArgs {
     long long ld, ldo;   // elements between consecutive positions (q/k/v and out)
     int fixed_len;       // > 0: sequences are frames of this length (cu/tile tables unused)
     float scale_log2;
+    // XCD-aware tile order (ntiles > 0): a 1-D grid of 8 * per_xcd blocks; block b works on the logical tile
+    // (b % 8) * per_xcd + b / 8 of the [head][tile] list, so every XCD (blocks are dealt round-robin over the 8 XCDs)
+    // walks a contiguous run of it: the query tiles of one (window, head) run side by side on ONE XCD and share the
+    // window's K/V through that XCD's L2 instead of each fetching them from HBM.
+    int ntiles, total, per_xcd;
 };
 
 template <int HD, int KT>
-__global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NTH, (HD <= 128 ? (KT <= 32 ? 3 : 2) : 1)) void flash_attn_kernel(const AttnArgs a) {
     constexpr int RB = HD * 2;            // bytes per K/V row
     constexpr int CPR = RB / 16;          // 16-byte chunks per row
     constexpr int KPI = 1024 / RB > 0 ? 1024 / RB : 1;  // keys per 1-KiB DMA instruction
@@ -45,14 +50,20 @@ __global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.y;
+    int head = blockIdx.y, tile = blockIdx.x;
+    if (a.ntiles > 0) {
+        const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+        if (logical >= a.total) return;   // whole workgroup: before any barrier
+        head = logical / a.ntiles;
+        tile = logical - head * a.ntiles;
+    }
     int q0, len;
     long long s0;
     if (a.fixed_len > 0) {
-        s0 = (long long)blockIdx.z * a.fixed_len; len = a.fixed_len; q0 = blockIdx.x * QT;
+        s0 = (long long)blockIdx.z * a.fixed_len; len = a.fixed_len; q0 = tile * QT;
     } else {
-        const int seq = a.tile_seq[blockIdx.x];
-        q0 = a.tile_q0[blockIdx.x];
+        const int seq = a.tile_seq[tile];
+        q0 = a.tile_q0[tile];
         s0 = a.cu[seq]; len = a.cu[seq + 1] - (int)s0;
     }
     const int l31 = lane & 31, hh = lane >> 5;
@@ -209,6 +220,243 @@ __global__ __launch_bounds__(NTH, (HD <= 128 ? 2 : 1)) void flash_attn_kernel(co
     }
 }
 
+// ---- second-generation window-attention kernel (HD = 128): same algorithm, same tile geometry and the same
+// summation order as flash_attn_kernel (bit-identical results for equal KT), but the LDS fragment reads are issued one
+// GROUP ahead of the MFMAs that consume them.  hipcc's own schedule of the kernel above is read -> s_waitcnt lgkmcnt(0)
+// -> MFMA for every single MFMA (one fragment register set, re-used), which exposes an LDS round trip (~100 cycles) in
+// front of each 32-cycle MFMA; here a group = the 8 K fragments of a 32-key half (QK^T) or the 8 transposed V reads of a
+// 16-key step (PV), two register sets, group g+1 is requested before the MFMAs of group g, and sched_barrier keeps that
+// order, so the compiler's counted lgkmcnt lets the MFMAs issue back to back.  The first V group is requested before
+// the softmax arithmetic, which hides it completely.
+template <int KT, bool AHEAD>
+__global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(const AttnArgs a) {
+    constexpr int HD = 128, RB = HD * 2, CPR = RB / 16, KPI = 1024 / RB;
+    constexpr int TILE_BYTES = KT * RB;
+    constexpr int NI = TILE_BYTES / 1024 / 4;
+    constexpr int NKS = HD / 16, NDT = HD / 32, NK2 = KT / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= a.total) return;
+    const int head = logical / a.ntiles;
+    const int tile = logical - head * a.ntiles;
+    const int seq = a.tile_seq[tile];
+    const int q0 = a.tile_q0[tile];
+    const long long s0 = a.cu[seq];
+    const int len = a.cu[seq + 1] - (int)s0;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const long long hoff = (long long)head * HD;
+
+    bf16x8 qf[NKS];
+    {
+        int qr = q0 + wave * 32 + l31;
+        if (qr > len - 1) qr = len - 1;
+        const bf16* qp = a.q + (s0 + qr) * a.ld + hoff + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+    const int lkey = lane / CPR, lslot = lane % CPR;
+    // K/V tile loader.  Full tiles: every lane keeps the byte offset of its NI pieces from the tile's first row (lane
+    // constants: key row and swizzled 16-byte chunk) and adds the tile's base, so a piece costs one 64-bit add; only a
+    // sequence's last, partial tile clamps its rows to the sequence (the address arithmetic of the clamped form is
+    // ~70 vector instructions per tile and wave, a quarter of the loop's VALU issue time when paid on every tile).
+    long long koffs[NI], voffs[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int key = (wave * NI + i) * KPI + lkey;
+        koffs[i] = ((long long)key * a.ld + ((lslot ^ (key & 15)) << 3)) * 2;
+        voffs[i] = ((long long)key * a.ld + ((lslot ^ ((key & 3) << 2)) << 3)) * 2;
+    }
+    const char* kseq = (const char*)(a.k + s0 * a.ld + hoff);
+    const char* vseq = (const char*)(a.v + s0 * a.ld + hoff);
+    const long long tile_step = (long long)KT * a.ld * 2;
+    auto issue = [&](int t, int stage) {
+        char* sK = smem + stage * TILE_BYTES;
+        char* sV = smem + (2 + stage) * TILE_BYTES;
+        if ((t + 1) * KT <= len) {
+            const char* kb = kseq + t * tile_step;
+            const char* vb = vseq + t * tile_step;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                glds16(kb + koffs[i], sK + (wave * NI + i) * 1024);
+                glds16(vb + voffs[i], sV + (wave * NI + i) * 1024);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int key = (wave * NI + i) * KPI + lkey;
+            int kr = t * KT + key;
+            if (kr > len - 1) kr = len - 1;
+            const long long row = (s0 + kr) * a.ld + hoff;
+            glds16(a.k + row + ((lslot ^ (key & 15)) << 3), sK + (wave * NI + i) * 1024);
+            glds16(a.v + row + ((lslot ^ ((key & 3) << 2)) << 3), sV + (wave * NI + i) * 1024);
+        }
+    };
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = a.scale_log2;
+    const int tg = (lane >> 4) & 1, ti = lane & 15;
+    const int tq = ti >> 2, tp = ti & 3;
+    int koff[8], voff[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) koff[j] = l31 * RB + (((((j ^ (l31 >> 1)) & 7) << 1) | (hh ^ (l31 & 1))) << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        voff[j] = (4 * hh + tq) * RB + (((((j ^ tq) & 3) << 2) | (2 * tg) | (tp >> 1)) << 4) + (tp & 1) * 8;
+
+    auto load_k = [&](const char* sK, int k2, bf16x8* kf) {
+        const char* kp = sK + k2 * 32 * RB;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kp + koff[ks]);
+    };
+    auto load_v = [&](const char* sV, int g, bf16x8* vf) {      // g = k2*2 + s: the 16-key step
+        const char* vrow = sV + g * 16 * RB;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const char* p0 = vrow + voff[dt];
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 8 * RB));
+            vf[dt] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+
+    const int nt = (len + KT - 1) / KT;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * TILE_BYTES;
+        const char* sV = smem + (2 + (t & 1)) * TILE_BYTES;
+
+        // ---- S^T = K . Q^T, fragment groups one ahead
+        f32x16 sacc[NK2];
+        bf16x8 vfa[NDT], vfb[NDT];
+        if constexpr (AHEAD) {
+            bf16x8 kfa[NKS], kfb[NKS];
+            load_k(sK, 0, kfa);
+#pragma unroll
+            for (int k2 = 0; k2 < NK2; ++k2) {
+                bf16x8* cur = (k2 & 1) ? kfb : kfa;
+                bf16x8* nxt = (k2 & 1) ? kfa : kfb;
+                if (k2 + 1 < NK2) load_k(sK, k2 + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ks], qf[ks], sacc[k2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the first V group travels while the softmax arithmetic runs
+            load_v(sV, 0, vfa);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < NK2; ++k2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
+                const char* kp = sK + k2 * 32 * RB;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kp + koff[ks]);
+                    sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
+                }
+            }
+        }
+
+        if (t == nt - 1 && (len % KT) != 0) {
+            const int kbase = t * KT + 4 * hh;
+#pragma unroll
+            for (int k2 = 0; k2 < NK2; ++k2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + k2 * 32 + (r & 3) + 8 * (r >> 2) >= len) sacc[k2][r] = -INFINITY;
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[k2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > RESCALE_THR) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
+        bf16x8 pf[NK2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[k2][r], c, -mc));
+                psum += p;
+                pf[k2][r >> 3][r & 7] = f2bf(p);
+            }
+        l_run += psum;
+
+        // ---- O^T += V^T . P^T (AHEAD: V groups one ahead)
+#pragma unroll
+        for (int g = 0; g < 2 * NK2; ++g) {
+            if constexpr (AHEAD) {
+                bf16x8* cur = (g & 1) ? vfb : vfa;
+                bf16x8* nxt = (g & 1) ? vfa : vfb;
+                if (g + 1 < 2 * NK2) load_v(sV, g + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[dt], pf[g >> 1][g & 1], oacc[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                load_v(sV, g, vfa);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[dt], pf[g >> 1][g & 1], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + wave * 32 + l31;
+    if (qr < len) {
+        const long long orow = a.out_rows ? (long long)a.out_rows[s0 + qr] : (long long)(s0 + qr);
+        bf16* op = a.out + orow * a.ldo + hoff + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[dt][g * 4 + e] * inv);
+                *(bf16x4*)(op + dt * 32 + g * 8) = o;
+            }
+    }
+}
+
+template <int KT, bool AHEAD>
+int launch_attn2(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int LDS = 4 * KT * 128 * 2;
+    SVR2_SET_MAX_LDS((flash_attn2_kernel<KT, AHEAD>), LDS, "flash_attn2");
+    hipLaunchKernelGGL((flash_attn2_kernel<KT, AHEAD>), grid, dim3(NTH), LDS, s, a);
+    SVR2_LAUNCH_CHECK();
+    return SVR2_OK;
+}
+
 template <int HD, int KT>
 int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int LDS = 4 * KT * HD * 2;
@@ -233,7 +481,20 @@ static int window_attn_impl(const void* q, const void* k, const void* v, void* o
     a.cu = cu_seqlens; a.tile_seq = tile_seq; a.tile_q0 = tile_q0; a.out_rows = out_rows;
     a.ld = (long long)H * 128; a.ldo = a.ld; a.fixed_len = 0;
     a.scale_log2 = scale * 1.4426950408889634f;
-    return launch_attn<128, 64>(a, dim3(ntiles, H, 1), (hipStream_t)stream);
+    a.ntiles = a.total = a.per_xcd = 0;
+    // SVR2_ATTN_V (A/B, profiles/r02_attn_*): 1 = 2-D grid in dispatch order (the round-1 kernel), 2 = XCD-aware tile
+    // order, 3 = that with 32-key tiles and three workgroups per CU, 4 = 64-key tiles with the fragment groups requested
+    // ahead, 5 (default) = 32-key tiles, three workgroups per CU, one-add DMA addressing, 6 = 64-key tiles with that
+    const int ver = svr2::opt(svr2::OPT_ATTN_V, 5);
+    if (ver == 1) return launch_attn<128, 64>(a, dim3(ntiles, H, 1), (hipStream_t)stream);
+    const long long total = (long long)ntiles * H;
+    SVR2_CHECK(total < (1ll << 30), SVR2_E_SHAPE, "svr2_window_attn: too many tiles");
+    a.ntiles = ntiles; a.total = (int)total; a.per_xcd = (int)((total + 7) / 8);
+    if (ver == 3) return launch_attn<128, 32>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
+    if (ver == 4) return launch_attn2<64, true>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);   // fragment groups ahead
+    if (ver == 5) return launch_attn2<32, false>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);  // cheap addressing, 3 WG/CU
+    if (ver == 6) return launch_attn2<64, false>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
+    return launch_attn<128, 64>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
 }
 
 extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens,

@@ -84,6 +84,30 @@ def bench_attn(grid, method, H=20):
     print(f"window_attn grid={grid} {method[:7]} S={S} nwin={pl.nwin}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
+def bench_attn_ab(grid, H=20, versions=(1, 2, 3), rounds=3):
+    """Same-process interleaved A/B of the window-attention variants (SVR2_ATTN_V) on both window methods."""
+    for method in (pkg.windows.REGULAR, pkg.windows.SHIFTED):
+        pl = pkg.windows.plan(grid, method, 58)
+        S = pl.total
+        q, k, v = rb(S, H, 128), rb(S, H, 128), rb(S, H, 128)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        cu, ts, tq = up(pl.cu_seqlens), up(pl.tile_seq), up(pl.tile_q0)
+        out = torch.empty_like(q)
+        lens = np.diff(pl.cu_seqlens).astype(np.float64)
+        fl = 4 * 128 * (lens ** 2).sum() * H
+        ref = None
+        for r in range(rounds):
+            for ver in versions:
+                hip.set_option("SVR2_ATTN_V", ver)
+                t = timeit(lambda: hip.window_attn(q, k, v, cu, ts, tq, 1 / math.sqrt(128), out), iters=10, warm=2)
+                if ref is None:
+                    ref = out.clone()
+                same = bool(torch.equal(out, ref))
+                print(f"window_attn v{ver} grid={grid} {method[:7]} H={H} S={S} nwin={pl.nwin} tiles={len(pl.tile_seq)}: "
+                      f"{t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s  bit-identical-to-v{versions[0]}={same}", flush=True)
+        hip.set_option("SVR2_ATTN_V", None)
+
+
 def bench_attn512(frames, P):
     qkv = rb(frames * P, 1536)
     out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
@@ -132,6 +156,11 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
+        vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,2,3").split(","))
+        bench_attn_ab((6, 135, 240), 20, vers)
+        if os.environ.get("SVR2_KB_ATTN_7B"):
+            bench_attn_ab((6, 135, 240), 24, vers, rounds=1)
     if "color" in which:
         bench_color(17, 2160, 3840)
     if "gn" in which:
