@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: upscaled frames/s (+ peak HBM) of the SeedVR2-3B hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg1]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg4|cfg5|cfg2|cfg1]
 
-A "step" is one pass of the hot path over one temporal batch of synthetic LR video on every rank:
-antialiased-bicubic transform -> causal VAE encode -> one-step NaDiT-3B -> causal VAE decode -> crop,
-Hann-blend of the `temporal_overlap` frames with the previous batch's tail; with N > 1 every rank owns
-its own contiguous frame segment (weak scaling along the frame-chunk axis) and after its batch sends the
-first `overlap` decoded frames to its left neighbour, which blends them into its tail (RCCL send/recv over
-xGMI) - the only exchange the path has.  Inputs are resident in HBM when the timed region starts; weights
-are random-init tensors of the real architecture (no checkpoints offline) -> "data": "synthetic".
+A "step" is one pass of the hot path over one temporal batch of the workload's synthetic LR clip on every rank:
+antialiased-bicubic transform -> causal VAE encode -> noise (CPU generator, like the reference's CPU path) + upload ->
+one-step NaDiT -> causal VAE decode -> crop, Hann-blend of the `temporal_overlap` frames with the previous batch's
+tail, write into the clip's output.  Steps cycle through the batches of the clip exactly as `generate()` walks them
+(cfg3: 64 frames, batch_size 21, overlap 4 -> batches of 21/21/21/13 frames, 4 steps = one clip = 64 finished frames),
+so `value` = finished frames / time over whole and partial clips.  With N > 1 every rank owns its own contiguous
+frame segment (weak scaling along the frame-chunk axis; cfg5: 64 frames + 4 overlap per rank = the reference's
+streaming split of a 512-frame clip over 8 GPUs) and, when its segment is complete, sends its first `overlap` finished
+frames to its left neighbour, which cross-fades them into its tail (RCCL send/recv over xGMI, parallel.py) - the only
+exchange the path has.  The LR clip is resident in HBM when the timed region starts (cfg5: as 8-bit container pixels,
+converted on the device per batch like the streaming reader does); weights are random-init tensors of the real
+architecture (no checkpoints offline) -> "data": "synthetic".
 
 Rank 0 prints ONE JSON line (see the driver contract in the task description).
 """
@@ -30,12 +35,13 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 WORKLOADS = {
-    # name: (frames per batch, LR h, LR w, resolution, temporal_overlap, description)
-    "cfg3": (21, 720, 1280, 2160, 4, "SeedVR2-3B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[2])"),
-    "cfg2": (9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8(+1 pad)-frame 540p->1080p (BASELINE configs[1])"),
-    "cfg1": (1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
-    "cfg2o": (9, 540, 960, 1080, 4, "rehearsal: cfg2 shape with temporal_overlap 4 (exercises the neighbour exchange)"),
-    "cfg4": (21, 720, 1280, 2160, 4, "SeedVR2-7B bf16, 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[3])"),
+    # name: (model, clip frames per rank, batch_size, LR h, LR w, resolution, temporal_overlap, description)
+    "cfg3": ("3b", 64, 21, 720, 1280, 2160, 4, "SeedVR2-3B bf16, 64-frame 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[2])"),
+    "cfg4": ("7b", 64, 21, 720, 1280, 2160, 4, "SeedVR2-7B bf16, 64-frame 720p->4K, batch_size 21, temporal_overlap 4 (BASELINE configs[3])"),
+    "cfg5": ("7b", 68, 21, 720, 1280, 2160, 4, "SeedVR2-7B bf16, 512-frame 720p->4K streamed, frame-chunk shard: 64 frames (+4 overlap) per rank (BASELINE configs[4])"),
+    "cfg2": ("3b", 8, 9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8-frame (padded to 9) 540p->1080p (BASELINE configs[1])"),
+    "cfg1": ("3b", 1, 1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
+    "cfg2o": ("3b", 26, 9, 540, 960, 1080, 4, "rehearsal: 540p->1080p clip of 26 frames, batch 9, overlap 4 (exercises blend + neighbour exchange)"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
@@ -96,25 +102,40 @@ class KernelTimer:
         return [f"{k}: calls={v[0]} time={v[1]*1e3:.1f}ms {v[2]/v[1]/1e12:.0f} TFLOP/s" for k, v in rows]
 
 
-def cpu_baseline(workload, n_threads):
-    """Reference CPU path (the oracle, a port) timed on a bounded sample on this host's cores and
-    extrapolated per stage by algorithmic FLOPs (336 TFLOP per 4K frame is days of CPU time)."""
+def cpu_baseline(workload, n_threads, pkg=None, vsd=None, dsd=None):
+    """Reference CPU path (the oracle, a port) timed on this host's cores on a bounded sample.
+    cfg1: the workload itself, end to end (transform -> encode -> NaDiT -> decode, bf16 like the reference's CPU path,
+    on the same synthetic weights as the GPU run).  Larger workloads: one full-width NaDiT block at 4,096 tokens and the
+    VAE on a 9-frame 128x128 clip, extrapolated per stage by algorithmic FLOPs (336 TFLOP per 4K frame is days of CPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from seedvr2_ref import dit as odit, vae as ovae
+    from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
     torch.set_num_threads(n_threads)
-    T, hin, win, res, ov, _ = WORKLOADS[workload]
-    # (a) one full-width NaDiT-3B block at 4,096 video tokens + 58 text tokens, bf16 like the reference CPU path
-    cfg = odit.DiTConfig(num_layers=2, mm_layers=1)
+    model, clip, T, hin, win, res, ov, _ = WORKLOADS[workload]
+    if workload == "cfg1" and vsd is not None and dsd is not None:
+        vp = {k: v.detach().cpu() for k, v in vsd.items()}
+        dp = {k: v.detach().cpu() for k, v in dsd.items()}
+        txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16)
+        lr = synth_lr_video(1, hin, win, 1234, "cpu").float()
+        t0 = time.time()
+        out = opipe.generate(lr, vp, ovae.VAEConfig(), dp, odit.CFG_3B, txt, res, 1, 0, 42, torch.bfloat16)
+        dt = time.time() - t0
+        assert tuple(out.shape[:3]) == (1, res, res)
+        return {"value": 1.0 / dt, "unit": "frames/s", "cores": n_threads, "kind": "port",
+                "sample": f"the whole cfg1 workload end to end through the oracle (bf16, torch CPU, {n_threads} threads): {dt:.1f} s"}
+    # (a) one full-width NaDiT block at 4,096 video tokens + 58 text tokens, bf16 like the reference CPU path
+    cfg = odit.DiTConfig(num_layers=2, mm_layers=1) if model == "3b" else \
+        odit.DiTConfig(vid_dim=3072, heads=24, num_layers=2, mm_layers=2, mlp_type="normal", out_norm=False, last_vid_only=False)
     p = {k: v.to(torch.bfloat16) for k, v in odit.synthetic_params(cfg, 0).items() if k.startswith("blocks.0.")}
     x = torch.randn(4096, cfg.vid_dim).to(torch.bfloat16)
     y = torch.randn(58, cfg.vid_dim).to(torch.bfloat16)
     emb = torch.randn(6 * cfg.vid_dim).to(torch.bfloat16)
-    odit.block(p, cfg, 0, x[:256], y, emb, (1, 16, 16), torch.bfloat16, "3b")  # warm the thread pool
+    rope = "3b" if model == "3b" else "7b"
+    odit.block(p, cfg, 0, x[:256], y, emb, (1, 16, 16), torch.bfloat16, rope)  # warm the thread pool
     t0 = time.time()
     for _ in range(3):
-        odit.block(p, cfg, 0, x, y, emb, (1, 64, 64), torch.bfloat16, "3b")
+        odit.block(p, cfg, 0, x, y, emb, (1, 64, 64), torch.bfloat16, rope)
     t_dit = (time.time() - t0) / 3
-    f_dit = 2 * 4096 * (2560 * 7680 + 2560 * 2560 + 3 * 2560 * 6912)
+    f_dit = _dit_flops(1, 1024, 1024, model) / (32 if model == "3b" else 36)
     del p
     # (b) the VAE on a 9-frame 128x128 clip (3 latent frames of 16x16), bf16
     vcfg = ovae.VAEConfig()
@@ -129,16 +150,17 @@ def cpu_baseline(workload, n_threads):
     f_enc, f_dec = _vae_flops(9, 128, 128)
     rate_dit, rate_enc, rate_dec = f_dit / t_dit, f_enc / t_enc, f_dec / t_dec
     _, _, _, _, ph, pw = ge.load_package().pipeline.target_dims(hin, win, res)
-    enc_f, dec_f = _vae_flops(T, ph, pw)
-    dit_f = _dit_flops(T, ph, pw)
-    t_step = enc_f / rate_enc + dec_f / rate_dec + dit_f / rate_dit
-    new_frames = T - ov
+    batches, _ = ge.load_package().pipeline.plan_batches(clip, T, ov)
+    t_clip = 0.0
+    for b in batches:
+        enc_f, dec_f = _vae_flops(len(b.index), ph, pw)
+        t_clip += enc_f / rate_enc + dec_f / rate_dec + _dit_flops(len(b.index), ph, pw, model) / rate_dit
     return {
-        "value": new_frames / t_step, "unit": "frames/s", "cores": n_threads, "kind": "port",
-        "sample": (f"oracle (bf16, torch CPU, {n_threads} threads): NaDiT-3B block @4096 tokens ({t_dit:.1f}s, "
+        "value": clip / t_clip, "unit": "frames/s", "cores": n_threads, "kind": "port",
+        "sample": (f"oracle (bf16, torch CPU, {n_threads} threads): NaDiT-{model} block @4096 tokens ({t_dit:.1f}s, "
                    f"{rate_dit/1e12:.2f} TFLOP/s) + VAE encode/decode of 9 frames 128x128 ({t_enc:.1f}s/{t_dec:.1f}s, "
                    f"{rate_enc/1e12:.2f}/{rate_dec/1e12:.2f} TFLOP/s), extrapolated per stage by algorithmic FLOPs to "
-                   f"the {workload} batch"),
+                   f"the {workload} clip ({clip} frames in batches of {[len(b.index) for b in batches]})"),
     }
 
 
@@ -173,7 +195,7 @@ def _dit_flops(T, H, W, model="3b"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("SVR2_BENCH_WORKLOAD", "cfg3"), choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,16 +223,23 @@ def main():
     hip = pkg.hip
     hip.device_check(local)
 
-    T, hin, win, res, overlap, desc = WORKLOADS[args.workload]
+    model, clip, bsz, hin, win, res, overlap, desc = WORKLOADS[args.workload]
+    if args.workload == "cfg5" and rank == world - 1:
+        clip -= overlap            # the last rank's segment has no overlap frames [ref: inference_cli.py:1091-1093]
     t_build = time.time()
     vcfg = pkg.vae.VAEConfig()
     if os.environ.get("SVR2_DECODE_SPLIT"):   # A/B of the temporal chunk sizes (results do not depend on them)
         vcfg.decode_split = int(os.environ["SVR2_DECODE_SPLIT"])
     if os.environ.get("SVR2_ENCODE_SPLIT"):
         vcfg.encode_split = int(os.environ["SVR2_ENCODE_SPLIT"])
-    vae = pkg.vae.VideoVAEHip(vcfg, pkg.vae.synthetic_state_dict(vcfg, dev, seed=1), dev)
-    dcfg = pkg.dit.CFG_7B if args.workload == "cfg4" else pkg.dit.CFG_3B
-    dit = pkg.dit.NaDiTHip(dcfg, pkg.dit.synthetic_state_dict(dcfg, dev, seed=2), dev)
+    vsd = pkg.vae.synthetic_state_dict(vcfg, dev, seed=1)
+    vae = pkg.vae.VideoVAEHip(vcfg, vsd, dev)
+    dcfg = pkg.dit.CFG_7B if model == "7b" else pkg.dit.CFG_3B
+    dsd = pkg.dit.synthetic_state_dict(dcfg, dev, seed=2)
+    dit = pkg.dit.NaDiTHip(dcfg, dsd, dev)
+    keep_sd = args.workload == "cfg1" and not args.no_cpu_baseline and world == 1   # the oracle runs the same weights
+    if not keep_sd:
+        vsd = dsd = None
     gtxt = torch.Generator(device="cpu").manual_seed(3)
     text_pos = (0.5 * torch.randn(58, 5120, generator=gtxt)).to(torch.bfloat16)  # shape of the shipped pos_emb.pt
     pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev)
@@ -218,12 +247,18 @@ def main():
     log(f"[rank {rank}] models built in {time.time() - t_build:.1f}s; weights {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
 
     rh, rw, th, tw, ph, pw = pkg.pipeline.target_dims(hin, win, res)
-    lr = synth_lr_video(T, hin, win, 1234 + rank, dev)            # resident in HBM before timing
-    latent_shape = ((T - 1) // 4 + 1, ph // 8, pw // 8, 16)
-    noise = pipe.make_noise(latent_shape, 42).to(dev)             # CPU-generator noise, uploaded once
+    batches, overlap = pkg.pipeline.plan_batches(clip, bsz, overlap)
+    nb = len(batches)
+    lr = synth_lr_video(clip, hin, win, 1234 + rank, dev)         # the rank's LR segment, resident in HBM before timing
+    streamed = args.workload == "cfg5"
+    if streamed:   # held as the container's 8-bit pixels; every batch is converted on the device like video_io's reader does
+        lr_u8 = (lr.float() * 255.0).round().to(torch.uint8).reshape(clip, -1).contiguous()
+        lay = pkg.video_io.Layout("rgb", win, hin)
+        del lr
+    idx_dev = [torch.tensor(b.index, device=dev) for b in batches]
     w_prev = pkg.pipeline.blend_weights(overlap).to(dev) if overlap else None
-    prev_tail = [None]
-    new_frames = T - overlap
+    final = torch.empty(clip, th, tw, 3, dtype=torch.bfloat16, device=dev)   # the clip's output, written batch by batch
+    state = {"write": 0, "frames": 0, "clips": 0}
 
     ktimer = KernelTimer()
     # the roofline kernel = conv_halo_kernel (all three geometries): the conv3d calls with the tiled weight layout
@@ -231,30 +266,41 @@ def main():
     hip.conv3d = ktimer.wrap(hip.conv3d, lambda out, x, w, cout, k, *a, **kw: 2.0 * out.numel() * x.shape[3] * k[0] * k[1] * k[2])
     pkg.vae.hip = hip
 
-    def step():
-        dec = pipe.upscale_batch(lr, res, 42, noise=noise)
-        sample = hip.crop_to_unit(dec, th, tw, to_unit=False)
+    def step(i):
+        """Batch i % nb of the clip through P1..P7, as SeedVR2Pipeline.generate walks it
+        [ref: src/core/generation_phases.py:342-521, 650-753, 904-1026, 1337]."""
+        bi = i % nb
+        b = batches[bi]
+        if bi == 0:
+            state["write"] = 0
+        if streamed:
+            frames = pkg.video_io.frames_from_bytes(lr_u8.index_select(0, idx_dev[bi]), lay)
+        else:
+            frames = lr.index_select(0, idx_dev[bi]).contiguous()
+        # transform, encode, noise drawn by the CPU generator and uploaded (inside the step), one-step DiT, decode
+        dec = pipe.upscale_batch(frames, res, 42)
+        sample = hip.crop_to_unit(dec[: b.ori_len].contiguous(), th, tw, to_unit=False)
         del dec
-        if overlap:
-            if prev_tail[0] is not None:  # blend with the previous batch's tail (same rank)
-                hip.blend_overlap(prev_tail[0], sample[:overlap].contiguous(), w_prev, prev_tail[0])
-            if world > 1:                 # segment boundary: head frames go to the left neighbour
-                ops = []
-                stage = (lambda t: t.cpu()) if backend == "gloo" else (lambda t: t)  # gloo p2p needs host tensors
-                recv = stage(torch.empty_like(sample[:overlap]))
-                if rank > 0:
-                    ops.append(dist.P2POp(dist.isend, stage(sample[:overlap].contiguous()), rank - 1))
-                if rank < world - 1:
-                    ops.append(dist.P2POp(dist.irecv, recv, rank + 1))
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
-                recv = recv.to(dev)
-                if rank < world - 1:
-                    tail = sample[-overlap:].contiguous()
-                    hip.blend_overlap(tail, recv, w_prev, tail)
-            prev_tail[0] = sample[-overlap:].clone()
-        out = hip.crop_to_unit(sample[: new_frames].contiguous() if overlap else sample, th, tw, to_unit=True)
-        return out
+        write = state["write"]
+        if bi > 0 and overlap and overlap < sample.shape[0] and write >= overlap:
+            tail = final[write - overlap:write]
+            hip.blend_overlap(tail.clone(), sample[:overlap].contiguous(), w_prev, tail)
+            sample = sample[overlap:]
+        n = sample.shape[0]
+        final[write:write + n] = sample
+        state["write"] = write + n
+        state["frames"] += n
+        if bi == nb - 1:                       # segment complete: [0,1] frames, then the boundary exchange
+            out = hip.crop_to_unit(final[: state["write"]], th, tw, to_unit=True)
+            if world > 1 and overlap:
+                if backend == "gloo":          # gloo p2p needs host tensors (rehearsal only)
+                    out = pkg.parallel.exchange_and_blend(out.float().cpu(), overlap, rank, world, dist).to(dev)
+                else:
+                    out = pkg.parallel.exchange_and_blend(out, overlap, rank, world, dist)
+                state["frames"] -= state["write"] - out.shape[0]   # frames handed to the left neighbour
+            state["clips"] += 1
+            return out
+        return None
 
     def barrier():
         torch.cuda.synchronize()
@@ -264,22 +310,26 @@ def main():
 
     for i in range(args.warmup):
         t0 = time.time()
-        step()
+        step(i)
         torch.cuda.synchronize()
-        log(f"[rank {rank}] warmup step {i}: {time.time() - t0:.2f}s")
+        log(f"[rank {rank}] warmup step {i} (batch of {len(batches[i % nb].index)} frames): {time.time() - t0:.2f}s")
     torch.cuda.reset_peak_memory_stats()
+    state.update(frames=0, clips=0)
     ktimer.enabled = True
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     ktimer.enabled = False
+    frames_done = state["frames"]
     if world > 1:
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt, 0.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        ff = torch.tensor([float(frames_done)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        dt, frames_done = float(tt[0].item()), int(ff.item())
     peak_gb = torch.cuda.max_memory_reserved() / 1e9
     log(f"[rank {rank}] peak reserved {peak_gb:.1f} GB, peak allocated {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
 
@@ -288,40 +338,49 @@ def main():
         if os.environ.get("SVR2_BENCH_TABLE"):
             for line in ktimer.table():
                 log("  conv3d", line)
-        enc_f, dec_f = _vae_flops(T, ph, pw)
-        dit_f = _dit_flops(T, ph, pw, "7b" if args.workload == "cfg4" else "3b")
+        per_batch = {}
+        for b in batches:
+            T = len(b.index)
+            enc_f, dec_f = _vae_flops(T, ph, pw)
+            per_batch[str(T)] = {"vae_encode": enc_f / 1e12, "dit_gemm": _dit_flops(T, ph, pw, model) / 1e12, "vae_decode": dec_f / 1e12}
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
-        traffic = None   # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this workload
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_cfg3.json")
-        if args.workload == "cfg3" and os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    traffic = json.load(fh)["kernels"]["conv3d halo-resident (conv_halo*_kernel)"]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        traffic, tsrc = None, None   # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this workload
+        for name in ("r02_hbm_traffic_cfg3.json", "r01_hbm_traffic_cfg3.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if args.workload == "cfg3" and os.path.exists(tpath):
+                try:
+                    with open(tpath) as fh:
+                        traffic = json.load(fh)["kernels"]["conv3d halo-resident (conv_halo*_kernel)"]["hbm_bytes_per_launch"]
+                    tsrc = name
+                    break
+                except Exception:
+                    traffic = None
+        metric = "upscaled frames/sec + peak HBM GB, SeedVR2-3B 720p->4K, 1/2/4/8 MI355X"
         result = {
-            "metric": "upscaled frames/sec + peak HBM GB, SeedVR2-3B 720p->4K, 1/2/4/8 MI355X",
-            "value": new_frames * world * args.steps / dt,
+            "metric": metric,
+            "value": frames_done / dt,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "peak_hbm_gb": peak_gb,
-            "config": {"workload": f"{args.workload}: {desc}", "frames_per_batch": T, "new_frames_per_step": new_frames,
+            "config": {"workload": f"{args.workload}: {desc}", "clip_frames_per_rank": clip, "batch_size": bsz,
+                       "temporal_overlap": overlap, "frames_per_batch": [len(b.index) for b in batches],
+                       "finished_frames": frames_done, "clips_completed_rank0": state["clips"],
                        "lr": [hin, win], "out": [th, tw], "padded": [ph, pw], "parallelism": f"frame-chunk x{world}",
-                       "algorithmic_tflop_per_step": {"vae_encode": enc_f / 1e12, "dit_gemm": dit_f / 1e12,
-                                                      "vae_decode": dec_f / 1e12}},
+                       "step": "one temporal batch of the clip (noise generation + upload inside), cycling through the clip's batches",
+                       "algorithmic_tflop_per_batch_by_frames": per_batch},
             "roofline": {"bound": "mfma", "kernel": "conv_halo_wr_kernel<16,256|32,128> + conv_halo_kernel<64,16> (halo-resident causal conv3d: every 3x3 stride-1 conv of the VAE)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic_cfg3.json)",
+                         "traffic_unit": f"bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 PMC, profiles/{tsrc})" if tsrc else None,
                          "algorithmic_flop_per_launch": kf / nl if nl else None,
                          "launches": nl, "kernel_time_s": kt, "share_of_step_time": kt / dt if dt > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.workload, min(os.cpu_count() or 1, 64))
+                result["cpu_baseline"] = cpu_baseline(args.workload, min(os.cpu_count() or 1, 64), pkg, vsd, dsd)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                           "sample": f"failed: {e!r}"}
