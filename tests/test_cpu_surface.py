@@ -140,3 +140,31 @@ def test_comfy_v3_schemas_mirror_the_reference_inputs(pkg, surface, monkeypatch)
     # inside ComfyUI the nodes answer with io.NodeOutput
     out = N.SeedVR2LoadVAEModel.execute(decode_tiled=True)
     assert isinstance(out, _IO.NodeOutput) and out[0]["decode_tiled"] is True
+
+
+def test_cli_defaults_and_node_specs_match_reference_literals(pkg, surface):
+    """Defaults / ranges read from the reference's own add_argument(...) and io.<Kind>.Input(...) calls (oracle/extract_surface.py)."""
+    cli = _cli(pkg)
+    a = vars(cli.parse_arguments(["in.png"]))
+    skip = {"--dit_model", "--output_format"}        # product default names the same file explicitly; extra container formats
+    for flag, want in surface["cli_defaults"].items():
+        if "#" in flag or flag in skip:
+            continue
+        assert a[flag.lstrip("-")] == want, (flag, a[flag.lstrip("-")], want)
+    assert a["dit_model"] == pkg.weights.DEFAULT_DIT
+    assert set(surface["cli_defaults"]["--color_correction#choices"]) == {"lab", "wavelet", "wavelet_adaptive", "hsv", "adain", "none"}
+    specs = {n: {s[0]: s for s in pkg.nodes._SCHEMAS[n]["inputs"]} for n in surface["node_inputs"]}
+    for node, inputs in surface["node_inputs"].items():
+        assert [s["name"] for s in inputs] == [s[0] for s in pkg.nodes._SCHEMAS[node]["inputs"]], node
+        for s in inputs:
+            mine = specs[node][s["name"]]
+            kind = s["kind"].replace("io.", "")
+            if kind.startswith("Custom"):
+                assert mine[1] == "Custom:" + kind.split('"')[1] if '"' in kind else kind.split("'")[1], (node, s)
+            else:
+                assert mine[1] == kind, (node, s["name"], mine[1], kind)
+            for key in ("default", "min", "max", "step"):
+                if key in s and not (node.startswith("SeedVR2Load") and s["name"] == "model"):
+                    assert mine[2].get(key) == s[key], (node, s["name"], key, mine[2].get(key), s[key])
+            if "options" in s and s["name"] in ("color_correction", "attention_mode", "tile_debug", "backend", "mode"):
+                assert mine[2]["options"] == s["options"], (node, s["name"])
