@@ -122,6 +122,42 @@ def test_cfg1_end_to_end_full_width(pkg, gpu, model):
     assert p_hip32 >= p_b16 - 3.0 and p_hip16 >= p_b16 - 3.0 and p_hip32 > 30.0
 
 
+def test_video_end_to_end_full_width_3b(pkg, gpu):
+    """The TEMPORAL path at the real architecture: a 9-frame clip (64x96 -> 128x192), batch_size 5, temporal_overlap 2
+    -> three overlapping batches (5, 5, 3 -> padded to 5 frames), causal conv carries across the VAE's temporal chunks,
+    4n+1 padding, Hann blend, `lab` colour correction off / on.  NaDiT-3B (32 layers x 2560) + VAE 128/256/512/512."""
+    from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    vsd = pkg.vae.synthetic_state_dict(pkg.vae.VAEConfig(), gpu, seed=1)
+    dsd = pkg.dit.synthetic_state_dict(pkg.dit.CFG_3B, gpu, seed=2)
+    vae = pkg.vae.VideoVAEHip(pkg.vae.VAEConfig(), vsd, gpu)
+    dit = pkg.dit.NaDiTHip(pkg.dit.CFG_3B, dsd, gpu)
+    vp, dp = _cpu_params(vsd), _cpu_params(dsd)
+    del vsd, dsd
+    txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).float()
+    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
+    g = torch.Generator().manual_seed(77)
+    low = 0.5 + 0.2 * torch.randn(9, 3, 8, 12, generator=g)
+    lr = torch.nn.functional.interpolate(low, size=(64, 96), mode="bicubic", align_corners=False).clamp(0, 1)
+    lr = ((lr * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
+    kw = dict(resolution=128, batch_size=5, temporal_overlap=2, seed=42)
+    row = {"input": "[9,64,96,3] -> 128x192, batch_size 5, temporal_overlap 2, seed 42"}
+    for cc in ("none", "lab"):
+        got = pipe.generate(lr, color_correction=cc, **kw).float().cpu()
+        t0 = time.time()
+        ref32 = opipe.generate(lr, vp, ovae.VAEConfig(), dp, odit.CFG_3B, txt, 128, 5, 2, 42, torch.float32, color_correction=cc).float()
+        ref16 = opipe.generate(lr, vp, ovae.VAEConfig(), dp, odit.CFG_3B, txt, 128, 5, 2, 42, torch.bfloat16, color_correction=cc).float()
+        assert got.shape == ref32.shape == (9, 128, 192, 3)
+        p_hip, p_b16, p_hb = psnr(got, ref32), psnr(ref16, ref32), psnr(got, ref16)
+        print(f"video full width (color_correction={cc}): PSNR hip vs fp32 {p_hip:.2f} dB (bf16 oracle vs fp32 {p_b16:.2f} dB), "
+              f"hip vs bf16 oracle {p_hb:.2f} dB, max|d| {float((got - ref32).abs().max()):.4f}; oracle {time.time() - t0:.0f}s")
+        row[cc] = {"psnr_hip_vs_fp32": p_hip, "psnr_bf16oracle_vs_fp32": p_b16, "psnr_hip_vs_bf16oracle": p_hb,
+                   "maxabs_hip_vs_fp32": float((got - ref32).abs().max()),
+                   "maxabs_bf16oracle_vs_fp32": float((ref16 - ref32).abs().max())}
+        assert p_hip >= p_b16 - 3.0 and p_hb >= p_b16 - 3.0 and p_hip > 30.0
+    _record("video9_3b", row)
+
+
 def test_dit_full_width_cfg2_grid(pkg, gpu):
     """NaDiT at full 3B width (2560, 20 heads, hidden 6912) with a separate-weights layer, a shared layer and the
     vid-only last layer on configs[1]'s DiT grid (3,68,120): 24 480 tokens, 75 regular / 90 shifted windows."""
