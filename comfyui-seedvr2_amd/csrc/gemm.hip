@@ -20,14 +20,18 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int B_TILE_BYTES = BN * BK * 2;         // 16 KiB
-// Two tile geometries share one kernel body (template parameter BM):
-//   BM = 128: 4 waves (2 x 2), 2-deep LDS ring (64 KiB), 2 workgroups per CU  - small problems / tails
-//   BM = 256: 8 waves (4 x 2), 3-deep LDS ring (144 KiB), counted vmcnt: two K-tiles of DMA stay in flight
-//             across the barrier, W traffic per FLOP halves                    - the large GEMMs / convs
-template <int BM> struct Geo {
+// Three geometries share one kernel body (template parameters BM, ST = depth of the LDS ring):
+//   BM = 128, ST 2: 4 waves (2 x 2), 2-deep LDS ring (64 KiB), 2 workgroups per CU  - small problems / tails
+//   BM = 256, ST 3: 8 waves (4 x 2), 3-deep LDS ring (144 KiB), counted vmcnt: two K-tiles of DMA stay in flight
+//             across the barrier, W traffic per FLOP halves                          - the large GEMMs / convs
+//   BM = 128, ST 4: the 128-row tile with a 4-deep ring (128 KiB, one workgroup per CU) and three K-tiles of DMA in
+//             flight - for tile-starved problems (at most one workgroup per CU anyway, e.g. the M = 1024 projections
+//             of a 512 x 512 image: 160 tiles on 256 CUs), where the 2-deep ring makes every K-step wait for a whole
+//             LDS-DMA round trip (measured 0.85 us per 64-deep step against 0.25 us of MFMA work)
+template <int BM, int ST> struct Geo {
     static constexpr int NT = BM * 2;                       // threads
     static constexpr int NW = NT / 64;                      // waves
-    static constexpr int STAGES = BM == 256 ? 3 : 2;
+    static constexpr int STAGES = ST;
     static constexpr int A_TILE_BYTES = BM * BK * 2;
     static constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // >= BM*BN*4 (fp32 epilogue tile)
@@ -36,9 +40,9 @@ template <int BM> struct Geo {
 
 using namespace svr2;
 
-template <int AMODE, int EPI, int BM>
+template <int AMODE, int EPI, int BM, int ST>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
-    using G = Geo<BM>;
+    using G = Geo<BM, ST>;
     constexpr int NTHREADS = G::NT, STAGE_BYTES = G::STAGE_BYTES, TILE_BYTES = G::A_TILE_BYTES, NBI = G::NBI;
     static_assert(G::LDS_BYTES >= BM * BN * 4, "epilogue tile must fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,21 +154,23 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / BK;
+    constexpr int S = G::STAGES, PT = 4 + NBI;   // PT: DMA instructions per thread and K-tile
     issue(0);
-    if (G::STAGES == 3 && nk > 1) issue(1);
+#pragma unroll
+    for (int i = 1; i < S - 1; ++i)
+        if (i < nk) issue(i);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // Tile kt must have landed for every wave, and every wave must be done reading the stage that is
-        // about to be refilled.  3-stage ring: leave the DMA of tile kt+1 in flight across the barrier
-        // (counted vmcnt = this thread's loads per tile); raw s_barrier, never __syncthreads (it drains vmcnt).
-        if (G::STAGES == 3) {
-            if (kt + 1 < nk) {
-                if (NBI == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            if (kt + 2 < nk) issue(stage >= 1 ? stage - 1 : 2);   // (kt + 2) % 3
+        // about to be refilled.  Rings of 3 and more stages leave the DMA of the next S-2 tiles in flight across the
+        // barrier (counted vmcnt = this thread's loads per tile x tiles); raw s_barrier, never __syncthreads (it
+        // drains vmcnt).
+        if (S >= 3) {
+            const int ahead = min(S - 2, nk - 1 - kt);
+            if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PT) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + S - 1 < nk) issue(stage == 0 ? S - 1 : stage - 1);   // (kt + S - 1) % S
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
         }
         const char* sA = smem + stage * STAGE_BYTES;
         const char* sB = sA + TILE_BYTES;
-        stage = (G::STAGES == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
+        stage = (stage == S - 1) ? 0 : stage + 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // (hipcc's own interleave of these reads and MFMAs measured 7 % faster than pinning
@@ -282,10 +288,10 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
     }
 }
 
-template <int AMODE, int EPI, int BM>
+template <int AMODE, int EPI, int BM, int ST>
 int launch_bm(KArgs a, hipStream_t s) {
-    using G = Geo<BM>;
-    SVR2_SET_MAX_LDS((gemm_kernel<AMODE, EPI, BM>), G::LDS_BYTES, "gemm");
+    using G = Geo<BM, ST>;
+    SVR2_SET_MAX_LDS((gemm_kernel<AMODE, EPI, BM, ST>), G::LDS_BYTES, "gemm");
     a.nbm = (a.M + BM - 1) / BM;
     a.nbn = (a.N + BN - 1) / BN;
     if (AMODE == A_CONV) {
@@ -293,7 +299,7 @@ int launch_bm(KArgs a, hipStream_t s) {
         a.cg.tiles_x = a.cg.Wo / 16;
         a.cg.tiles_y = a.cg.Ho / (BM / 16);
     }
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, BM>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, BM, ST>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS_BYTES, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
@@ -323,7 +329,12 @@ int launch(const KArgs& a, hipStream_t s) {
     if (((ver == 2 && tiles2 >= 384 && v2_shape) || ver == 3) && a.K % 32 == 0)
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
-    return big ? launch_bm<AMODE, EPI, 256>(a, s) : launch_bm<AMODE, EPI, 128>(a, s);
+    if (big) return launch_bm<AMODE, EPI, 256, 3>(a, s);
+    // tile-starved dense problems (at most one 128 x 128 workgroup per CU): the 4-deep ring; SVR2_GEMM_DEEP=0 for A/B
+    const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (AMODE == A_DENSE && tiles1 <= 288 && a.K >= 512 && svr2::opt(svr2::OPT_GEMM_DEEP, 1) != 0)
+        return launch_bm<AMODE, EPI, 128, 4>(a, s);
+    return launch_bm<AMODE, EPI, 128, 2>(a, s);
 }
 
 }  // namespace
@@ -331,9 +342,10 @@ int launch(const KArgs& a, hipStream_t s) {
 // ---- tuning switches and per-device bookkeeping (common.h)
 namespace svr2 {
 static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
-                                                 "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V"};
+                                                 "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V",
+                                                 "SVR2_GEMM_DEEP"};
 static const int kUnset = INT32_MIN;
-static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
 static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
 
 int opt(Opt o, int dflt) {

@@ -45,6 +45,22 @@ def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, lib_option):
     assert_close(out, a @ w.T + b, f"gemm4 {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 2560, 2560), (1000, 2560, 6912), (58, 2560, 512), (1024, 384, 576), (300, 3072, 12288)])
+def test_gemm_deep_ring_tile_starved(pkg, gpu, M, N, K, lib_option):
+    """gemm.hip, 128-row tile with the 4-deep LDS ring (tile-starved dense problems, e.g. the M = 1024 projections of a
+    512 x 512 image): same summation order as the 2-deep ring -> bit-identical to it, and within tolerance of fp32."""
+    hip = pkg.hip
+    a, w = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=1 / math.sqrt(K))
+    bias, gate, res = rnd(N, seed=13), rnd(N, seed=14), rnd(M, N, seed=15)
+    wd = hip.pad_weight(w.to(gpu))
+    args = dict(epilogue=hip.EPI_GATE_RES, bias=bias.to(gpu), gate=gate.to(gpu), resid=dev_bf16(res, gpu))
+    deep = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
+    lib_option("SVR2_GEMM_DEEP", 0)
+    shallow = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
+    assert torch.equal(deep, shallow)
+    assert_close(deep, res + gate * (a @ w.T + bias), f"gemm deep ring {M}x{N}x{K}")
+
+
 def test_gemm4_pingpong_epilogues(pkg, gpu, lib_option):
     lib_option("SVR2_GEMM_V", 3)
     hip = pkg.hip
