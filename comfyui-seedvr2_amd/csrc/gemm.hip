@@ -330,9 +330,12 @@ int launch(const KArgs& a, hipStream_t s) {
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
     if (big) return launch_bm<AMODE, EPI, 256, 3>(a, s);
-    // tile-starved dense problems (at most one 128 x 128 workgroup per CU): the 4-deep ring; SVR2_GEMM_DEEP=0 for A/B
+    // tile-starved dense problems (at most one 128 x 128 workgroup per CU): SVR2_GEMM_DEEP=1 selects the 4-deep ring.
+    // Measured (tools/kernel_bench.py gemmsmallm, M = 1024): 38 us either way for N = K = 2560 - these shapes are
+    // bound by the rate at which a CU accepts 1-KiB LDS-DMA pieces (32 per 128 x 128 x 64 step, ~45 cycles each), not
+    // by the DMA latency the deeper ring hides; off by default.
     const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (AMODE == A_DENSE && tiles1 <= 288 && a.K >= 512 && svr2::opt(svr2::OPT_GEMM_DEEP, 1) != 0)
+    if (AMODE == A_DENSE && tiles1 <= 288 && a.K >= 512 && svr2::opt(svr2::OPT_GEMM_DEEP, 0) != 0)
         return launch_bm<AMODE, EPI, 128, 4>(a, s);
     return launch_bm<AMODE, EPI, 128, 2>(a, s);
 }

@@ -54,6 +54,7 @@ def test_gemm_deep_ring_tile_starved(pkg, gpu, M, N, K, lib_option):
     bias, gate, res = rnd(N, seed=13), rnd(N, seed=14), rnd(M, N, seed=15)
     wd = hip.pad_weight(w.to(gpu))
     args = dict(epilogue=hip.EPI_GATE_RES, bias=bias.to(gpu), gate=gate.to(gpu), resid=dev_bf16(res, gpu))
+    lib_option("SVR2_GEMM_DEEP", 1)
     deep = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
     lib_option("SVR2_GEMM_DEEP", 0)
     shallow = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
