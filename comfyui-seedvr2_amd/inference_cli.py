@@ -36,7 +36,8 @@ class Runtime:
                  dist_backend: str = "nccl", child_cmd: Optional[List[str]] = None, poll_seconds: float = 0.2):
         self.device_for = device_for or (lambda dev_id: f"cuda:{dev_id}")
         self.set_device = set_device or (lambda dev: torch.cuda.set_device(torch.device(dev)))
-        self.dist_backend = dist_backend
+        # SVR2_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several ranks on ONE GPU)
+        self.dist_backend = os.environ.get("SVR2_DIST_BACKEND", dist_backend)
         self.child_cmd = child_cmd or [sys.executable, os.path.abspath(__file__)]
         self.poll_seconds = poll_seconds
 
@@ -176,7 +177,10 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
         return pkg.nodes.SeedVR2VideoUpscaler.run_device(
             frames, dit_cfg, vae_cfg, a.seed, a.resolution, a.max_resolution, a.batch_size, a.uniform_batch_size,
             a.temporal_overlap, prepend, a.color_correction, text_pos=text_pos, input_noise_scale=a.input_noise_scale,
-            latent_noise_scale=a.latent_noise_scale)
+            latent_noise_scale=a.latent_noise_scale,
+            # one GPU: the reference never strips the warm-up frames' outputs [ref: inference_cli.py:920]; several GPUs:
+            # its parent strips them after concatenation [ref: :1200-1204] = rank 0 strips them here
+            keep_prepended=(world == 1))
 
     def sink_for(w, h):
         return vio.DeviceSink(vio.open_writer(output_path, w, h, reader.fps, base_name, single_image=itype == "image",

@@ -246,9 +246,12 @@ class SeedVR2VideoUpscaler(_Base):
                    max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
                    temporal_overlap: int = 0, prepend_frames: int = 0, color_correction: str = "lab",
                    text_pos: torch.Tensor | None = None, pipeline=None, input_noise_scale: float = 0.0,
-                   latent_noise_scale: float = 0.0) -> torch.Tensor:
+                   latent_noise_scale: float = 0.0, keep_prepended: bool = False) -> torch.Tensor:
         """The upscaler without the host round trip: image [N,H,W,3] in [0,1] (any device / float dtype; bf16 frames that
-        are already on the device are used as they are) -> bf16 [N,H',W',3] in [0,1] on the device."""
+        are already on the device are used as they are) -> bf16 [N,H',W',3] in [0,1] on the device.
+        keep_prepended: leave the outputs of the `prepend_frames` warm-up frames in the result -- what the reference's
+        single-GPU CLI does (it passes prepend_frames=0 to postprocess_all_batches, inference_cli.py:920, and only its
+        multi-GPU parent strips them, :1200-1204); the node path strips them (generation_phases.py:1377-1386)."""
         pipe = pipeline or _build_pipeline(dit, vae, text_pos)
         # tiling is a property of the VAE node's settings, not of the cached pipeline
         pipe.set_tiling(**{k: vae[k] for k in ("encode_tiled", "encode_tile_size", "encode_tile_overlap", "decode_tiled",
@@ -258,7 +261,7 @@ class SeedVR2VideoUpscaler(_Base):
                             progress=_check_interrupt, color_correction=color_correction,
                             input_noise_scale=input_noise_scale, latent_noise_scale=latent_noise_scale)
         # postprocess_all_batches removes them again [ref: src/core/generation_phases.py:1377-1386]
-        if prepend_frames > 0 and prepend_frames < out.shape[0]:
+        if prepend_frames > 0 and prepend_frames < out.shape[0] and not keep_prepended:
             out = out[prepend_frames:]
         return out
 

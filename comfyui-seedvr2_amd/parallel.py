@@ -65,6 +65,15 @@ def blend_weights_f32(overlap: int, device=None) -> torch.Tensor:
     return torch.linspace(1.0, 0.0, steps=overlap, dtype=torch.float32, device=device)
 
 
+def _host_staged(frames: torch.Tensor, dist) -> bool:
+    """gloo moves host memory only: device frames are staged through the host (rehearsals of the multi-rank control
+    flow, e.g. several ranks on one GPU); RCCL ("nccl") sends device memory over xGMI as it is."""
+    try:
+        return frames.is_cuda and dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
 def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int, dist=None) -> torch.Tensor:
     """frames: this rank's finished frames [T,H,W,C] (any float dtype, on the rank's device).
     Returns the frames this rank owns after the boundary exchange: tail blended with the right neighbour's
@@ -75,8 +84,10 @@ def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int
     if dist is None:
         import torch.distributed as dist
     T = frames.shape[0]
+    staged = _host_staged(frames, dist)
+    cdev = "cpu" if staged else frames.device
     # frame counts of the neighbours decide whether a boundary is blended (reference: chunk.shape[0] > overlap)
-    counts = torch.zeros(world, dtype=torch.int64, device=frames.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
     counts[rank] = T
     dist.all_reduce(counts)  # tiny control message (8 bytes per rank)
     counts = counts.tolist()
@@ -85,12 +96,15 @@ def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int
     send_ok = rank > 0 and T > overlap and counts[rank - 1] >= overlap
     recv_ok = rank < world - 1 and counts[rank + 1] > overlap and T >= overlap
     if send_ok:
-        reqs.append(dist.isend(frames[:overlap].contiguous(), rank - 1))
+        head = frames[:overlap].contiguous()
+        reqs.append(dist.isend(head.cpu() if staged else head, rank - 1))
     if recv_ok:
-        recv = torch.empty_like(frames[:overlap])
+        recv = torch.empty_like(frames[:overlap], device=cdev)
         reqs.append(dist.irecv(recv, rank + 1))
     for r in reqs:
         r.wait()
+    if recv is not None and staged:
+        recv = recv.to(frames.device)
     out = frames
     if recv_ok:
         w = blend_weights_f32(overlap, frames.device).view(overlap, *([1] * (frames.dim() - 1)))
@@ -108,22 +122,24 @@ def gather_frames(frames: torch.Tensor, rank: int, world: int, dst: int = 0, dis
         return frames
     if dist is None:
         import torch.distributed as dist
-    counts = torch.zeros(world, dtype=torch.int64, device=frames.device)
+    staged = _host_staged(frames, dist)
+    cdev = "cpu" if staged else frames.device
+    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
     counts[rank] = frames.shape[0]
     dist.all_reduce(counts)
     counts = counts.tolist()
     if rank != dst:
         if frames.shape[0] > 0:
-            dist.send(frames.contiguous(), dst)
+            dist.send(frames.contiguous().cpu() if staged else frames.contiguous(), dst)
         return None
     parts = []
     for r in range(world):
         if r == dst:
             parts.append(frames)
         elif counts[r] > 0:
-            buf = torch.empty((counts[r],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+            buf = torch.empty((counts[r],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=cdev)
             dist.recv(buf, r)
-            parts.append(buf)
+            parts.append(buf.to(frames.device) if staged else buf)
     return torch.cat(parts, dim=0)
 
 

@@ -376,13 +376,43 @@ def test_cli_from_checkpoint_files(pkg, gpu, tmp_path, monkeypatch):
     assert rc == 0
 
     def core(x, prepend):
-        y = pkg.nodes.SeedVR2VideoUpscaler.run_device(x.to(gpu), {}, {}, 7, 48, 0, 5, False, 1, prepend, "wavelet", pipeline=pipe)
+        # the reference's single-GPU worker returns the warm-up frame's output as well (inference_cli.py:920)
+        y = pkg.nodes.SeedVR2VideoUpscaler.run_device(x.to(gpu), {}, {}, 7, 48, 0, 5, False, 1, prepend, "wavelet", pipeline=pipe,
+                                                      keep_prepended=True)
         return y.cpu()
 
     outs = torch.cat(ovio.stream_chunks(ovio.u8_to_unit(clip[1:]), 3, 1, 1, core), dim=0)
-    assert outs.shape == (6, 48, 64, 3)
+    assert outs.shape == (7, 48, 64, 3)          # 6 frames + the prepended one, like the reference's single-GPU CLI
     r = vio.open_reader(str(tmp_path / "clip_out.y4m"))
-    assert (r.total_frames, r.width, r.height, r.fps) == (6, 64, 48, 25.0)
-    raw = np.empty((6, r.layout.frame_bytes), np.uint8)
-    assert r.read_into(raw, 6) == 6
+    assert (r.total_frames, r.width, r.height, r.fps) == (7, 64, 48, 25.0)
+    raw = np.empty((7, r.layout.frame_bytes), np.uint8)
+    assert r.read_into(raw, 7) == 7
     assert np.array_equal(raw, ovio.rgb_to_yuv(ovio.unit_to_u8(outs), 2))
+
+    # SURVEY 8e on the device: `--cuda_device 0,0` makes the CLI fan out into two worker processes (here both on this
+    # box's one GPU, exchanging over gloo because RCCL needs distinct GPUs): segment split, per-rank chunk streaming,
+    # neighbour exchange + cross-fade on the devices, gather, rank 0 writes -- byte-equal to the reference's multi-GPU
+    # semantics (inference_cli.py:1082-1097, 1163-1204) computed here around the same pipeline.
+    clip2 = np.random.default_rng(36).integers(0, 256, size=(14, 24, 32, 3), dtype=np.uint8)
+    np.save(tmp_path / "clip2.npy", clip2)
+    monkeypatch.setenv("SVR2_DIST_BACKEND", "gloo")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = cli.main([str(tmp_path / "clip2.npy"), "--resolution", "48", "--batch_size", "5", "--seed", "7", "--temporal_overlap", "2",
+                   "--prepend_frames", "1", "--color_correction", "none", "--model_dir", str(mdir), "--cuda_device", "0,0",
+                   "--output", str(tmp_path / "clip2_out.npy")])
+    assert rc == 0
+    got2 = np.load(tmp_path / "clip2_out.npy")
+    frames2 = ovio.u8_to_unit(clip2)
+    parts = []
+    for r_, (s_, e_) in enumerate(pkg.parallel.segment_ranges(14, 2, 2, 5, True)):
+        y = pkg.nodes.SeedVR2VideoUpscaler.run_device(frames2[s_:e_].to(gpu), {}, {}, 7, 48, 0, 5, False, 2, 1 if r_ == 0 else 0, "none",
+                                                      pipeline=pipe)          # rank 0 prepends and strips, like the reference
+        parts.append(y.float().cpu())
+    ov, acc = 2, parts[0]
+    w_prev = pkg.parallel.blend_weights_f32(ov).view(ov, 1, 1, 1)
+    blended = (acc[-ov:] * w_prev + parts[1][:ov] * (1.0 - w_prev)).to(torch.bfloat16).float()
+    want2 = torch.cat((acc[:-ov], blended, parts[1][ov:]), dim=0)
+    assert got2.shape == (14, 48, 64, 3)
+    exp2 = ovio.unit_to_u8(want2.to(torch.bfloat16))
+    per_frame = [(int((got2[i] != exp2[i]).sum()), int(np.abs(got2[i].astype(int) - exp2[i].astype(int)).max())) for i in range(14)]
+    assert np.array_equal(got2, exp2), f"(mismatching bytes, max level difference) per frame: {per_frame}"
