@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256) void hue_map_kernel(const unsigned long long* 
         long long j = r;
         if (ns != nr) {
             const float step = __fdiv_rn(1.f, (float)(ns - 1));
-            const float q = r < ns / 2 ? __fmul_rn(step, (float)r) : __fsub_rn(1.f, __fmul_rn(step, (float)(ns - r - 1)));
+            // torch's linspace: start + step*i below the midpoint, end - step*(n-1-i) above it, the latter evaluated as ONE
+            // fused multiply-add by ATen's vectorised CPU kernel (checked bit for bit by test_hue_sat_match_quantiles_exact)
+            const float q = r < ns / 2 ? __fmul_rn(step, (float)r) : __builtin_fmaf(-step, (float)(ns - r - 1), 1.f);
             j = (long long)__fmul_rn(q, (float)(nr - 1));
             j = j < 0 ? 0 : (j > nr - 1 ? nr - 1 : j);
         }
