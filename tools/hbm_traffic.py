@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) into
-profiles/r01_hbm_traffic_cfg3.json: HBM-side bytes per kernel family and per launch.
+profiles/r0x_hbm_traffic_cfg3.json: HBM-side bytes per kernel family and per launch.
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- \\
       python3 bench.py --workload cfg3 --steps 1 --warmup 0 --no-cpu-baseline
@@ -39,7 +39,7 @@ def load(d, cname):
 def main():
     fdir, wdir, out = sys.argv[1:4]
     f, w = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
-    res = {"source": __doc__.strip().splitlines()[0] + " One bench step (cfg3), round-1 final kernels; FETCH_SIZE x2, KB -> bytes; "
+    res = {"source": __doc__.strip().splitlines()[0] + " One bench step (cfg3: first temporal batch, 21 frames); FETCH_SIZE x2, KB -> bytes; "
            "per launch = total / launches.", "kernels": {}}
     tot = 0.0
     for k in sorted(set(f) | set(w), key=lambda k: -(f[k][1] * 2 + w[k][1])):
