@@ -173,7 +173,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
     int tm, tn;
     tile_coords(a, tm, tn);
     const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
-    const int t = tm / per_frame, rem = tm - t * per_frame;
+    // patch == 3: frame-fastest tile order (the To tiles of one patch are neighbours in an XCD's run, so the temporal
+    // taps they share are re-read from that XCD's L2 instead of HBM)
+    const int t = a.cg.patch == 3 ? tm % a.cg.To : tm / per_frame;
+    const int rem = a.cg.patch == 3 ? tm / a.cg.To : tm - t * per_frame;
     const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
     const int y0 = ty * G::PH, x0 = tx * PW, n0 = tn * BN;
     const int Cin = a.cg.Cin, Wi = a.cg.Wi, Hi = a.cg.Hi;
@@ -321,7 +324,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     int tm, tn;
     tile_coords(a, tm, tn);
     const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
-    const int t = tm / per_frame, rem = tm - t * per_frame;
+    // patch == 3: frame-fastest tile order (the To tiles of one patch are neighbours in an XCD's run, so the temporal
+    // taps they share are re-read from that XCD's L2 instead of HBM)
+    const int t = a.cg.patch == 3 ? tm % a.cg.To : tm / per_frame;
+    const int rem = a.cg.patch == 3 ? tm / a.cg.To : tm - t * per_frame;
     const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
     const int y0 = ty * G::PH, x0 = tx * PW, n0 = tn * BN;
     const int Cin = a.cg.Cin, Wi = a.cg.Wi, Hi = a.cg.Hi;
@@ -432,7 +438,7 @@ int launch_halo(KArgs a, hipStream_t s) {
     if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN>;
     else fn = (const void*)conv_halo_kernel<PW, BN>;
     SVR2_SET_MAX_LDS(fn, G::LDS, "conv_halo");
-    a.cg.patch = 2;
+    a.cg.patch = svr2::opt(svr2::OPT_CONV_TFAST, 0) ? 3 : 2;
     a.cg.tiles_x = (a.cg.Wo + PW - 1) / PW;
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
     a.nbm = a.cg.To * a.cg.tiles_x * a.cg.tiles_y;

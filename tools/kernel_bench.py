@@ -195,6 +195,16 @@ if __name__ == "__main__":
         for shp in ((4, 2160, 3840, 128, 128), (4, 1080, 1920, 256, 256), (2, 540, 960, 512, 512)):
             bench_conv(*shp, tiled=True)
             bench_conv(*shp, tiled=True, resid=True)
+    if "halotfast" in which:   # same-box A/B of the frame-fastest tile order (SVR2_CONV_TFAST)
+        for rnd in range(3):
+            for v in (0, 1):
+                hip.set_option("SVR2_CONV_TFAST", v)
+                print(f"-- round {rnd} SVR2_CONV_TFAST={v}", flush=True)
+                bench_conv(4, 2160, 3840, 128, 128, tiled=True)
+                bench_conv(4, 1080, 1920, 256, 256, tiled=True)
+                bench_conv(4, 1080, 1920, 512, 512, tiled=True)
+                bench_conv(8, 1080, 1920, 256, 256, tiled=True)
+        hip.set_option("SVR2_CONV_TFAST", None)
     if "halopmc" in which:   # few launches of the three dominant halo-conv shapes for counter collection
         bench_conv(4, 2160, 3840, 128, 128, tiled=True)
         bench_conv(4, 1080, 1920, 256, 256, tiled=True)
