@@ -310,7 +310,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 //     and meets it only at the slice barrier, so it keeps the MFMA pipe fed meanwhile.
 //   * The nine taps of a slice are straight-line code so that the compiler's counted vmcnt waits stay exact (a branch
 //     between a load and its use makes it fall back to vmcnt(0)); sched_barrier pins each load two taps before its use.
-template <int PW, int BN>
+//   * SPLIT (small grids, see conv_halo_split): blockIdx.x = tile * S + ks; the workgroup multiplies only the channel
+//     slices [ks * nsl / S, (ks + 1) * nsl / S) and stores its fp32 accumulators as a register image; conv_halo_finish_kernel
+//     adds the S images of a tile in the order ks = 0..S-1 (deterministic) and runs the shared epilogue.
+template <int PW, int BN, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
     constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK;
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool hrole = wave >= 4;
     int tm, tn;
-    tile_coords(a, tm, tn);
+    const int ks = SPLIT ? (int)(blockIdx.x & ((1u << a.ks_log2) - 1)) : 0;
+    tile_coords(a, SPLIT ? (int)(blockIdx.x >> a.ks_log2) : (int)blockIdx.x, tm, tn);
     const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
     // patch == 3: frame-fastest tile order (the To tiles of one patch are neighbours in an XCD's run, so the temporal
     // taps they share are re-read from that XCD's L2 instead of HBM)
@@ -387,17 +391,19 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         }
     };
 
-    if (hrole) issue_halo(slice_base(0, 0), halo0);
-    load_w(0, 0);
-    load_w(1, 1);
-    load_w(2, 2);
+    const int sl0 = SPLIT ? (ks * nsl) >> a.ks_log2 : 0;
+    const int sl1 = SPLIT ? ((ks + 1) * nsl) >> a.ks_log2 : nsl;
+    int tap_t = SPLIT ? sl0 / ncs : 0, cs = SPLIT ? sl0 - tap_t * ncs : 0, hb = 0;
+    if (hrole) issue_halo(slice_base(tap_t, cs), halo0);
+    load_w(0, sl0 * 9);
+    load_w(1, sl0 * 9 + 1);
+    load_w(2, sl0 * 9 + 2);
 
-    int tap_t = 0, cs = 0, hb = 0;
-    for (int sl = 0; sl < nsl; ++sl) {
+    for (int sl = sl0; sl < sl1; ++sl) {
         // the halo of this slice has landed for every wave and every wave is done reading the other buffer
         if (hrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        if (hrole && sl + 1 < nsl) {
+        if (hrole && sl + 1 < sl1) {
             if (++cs == ncs) { cs = 0; ++tap_t; }
             issue_halo(slice_base(tap_t, cs), halo0 + (hb ^ 1) * G::HALO_BYTES);
         }
@@ -427,15 +433,73 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         }
         hb ^= 1;
     }
+    if constexpr (SPLIT) {
+        f32x4* img = (f32x4*)a.partial + ((((long long)(tm * a.nbn + tn)) << a.ks_log2) + ks) * (MI * JN * G::NT) + tid;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j) img[(i * JN + j) * G::NT] = acc[i][j];
+        return;
+    }
     asm volatile("s_barrier" ::: "memory");
     halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
+}
+
+// Second launch of a split conv: one workgroup per tile adds the S accumulator images in split order and finishes the
+// tile exactly like the unsplit kernel does (bias, bf16 rounding, residual, GroupNorm partial sums).
+template <int PW, int BN>
+__global__ __launch_bounds__(512, 2) void conv_halo_finish_kernel(const KArgs a) {
+    using G = GeoH<PW, BN>;
+    constexpr int WPX = PW / 16, NWN = 8 / WPX, CPW = BN / NWN, JN = CPW / 16, MI = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    tile_coords(a, tm, tn);
+    const int per_frame = a.cg.tiles_x * a.cg.tiles_y;
+    const int t = a.cg.patch == 3 ? tm % a.cg.To : tm / per_frame;
+    const int rem = a.cg.patch == 3 ? tm / a.cg.To : tm - t * per_frame;
+    const int ty = rem / a.cg.tiles_x, tx = rem - ty * a.cg.tiles_x;
+    const int y0 = ty * G::PH, x0 = tx * PW, n0 = tn * BN;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int wpx0 = wm * 16;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int pix = frow < 4 ? 2 * frow : (frow < 12 ? 2 * frow - 7 : 2 * frow - 16);
+    const int S = 1 << a.ks_log2;
+    const f32x4* img = (const f32x4*)a.partial + (((long long)(tm * a.nbn + tn)) << a.ks_log2) * (MI * JN * G::NT) + tid;
+    f32x4 acc[MI][JN];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j) acc[i][j] = img[(i * JN + j) * G::NT];
+    for (int k = 1; k < S; ++k) {
+        img += MI * JN * G::NT;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                const f32x4 v = img[(i * JN + j) * G::NT];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += v[r];
+            }
+    }
+    halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
+}
+
+// K splits of a W-through-registers conv: the latent-resolution 512-channel convs of a small image are 16-128 tiles for
+// 256 CUs with a K loop of 48 slices; splitting the slices S ways fills the chip.  Power of two, >= 6 slices per split.
+static int conv_halo_split(long long tiles, int nsl) {
+    if (!svr2::opt(svr2::OPT_CONV_SPLIT, 1)) return 0;
+    int lg = 0;
+    while ((tiles << lg) < 192 && lg < 3 && (nsl >> (lg + 1)) >= 6) ++lg;
+    return lg;
 }
 
 template <int PW, int BN, bool WR>
 int launch_halo(KArgs a, hipStream_t s) {
     using G = GeoH<PW, BN>;
     const void* fn;
-    if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN>;
+    if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN, false>;
     else fn = (const void*)conv_halo_kernel<PW, BN>;
     SVR2_SET_MAX_LDS(fn, G::LDS, "conv_halo");
     a.cg.patch = svr2::opt(svr2::OPT_CONV_TFAST, 0) ? 3 : 2;
@@ -443,10 +507,35 @@ int launch_halo(KArgs a, hipStream_t s) {
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
     a.nbm = a.cg.To * a.cg.tiles_x * a.cg.tiles_y;
     a.nbn = (a.N + BN - 1) / BN;
-    if constexpr (WR) hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    if constexpr (WR) {
+        const long long tiles = (long long)a.nbm * a.nbn;
+        const int lg = a.partial ? conv_halo_split(tiles, a.cg.kt * (a.cg.Cin / G::BK)) : 0;
+        if (lg > 0 && (size_t)(tiles << lg) * G::BM * BN * 4 <= a.partial_bytes) {
+            SVR2_SET_MAX_LDS((const void*)(conv_halo_wr_kernel<PW, BN, true>), G::LDS, "conv_halo (split)");
+            SVR2_SET_MAX_LDS((const void*)(conv_halo_finish_kernel<PW, BN>), G::EPI_BYTES, "conv_halo (finish)");
+            a.ks_log2 = lg;
+            hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, true>), dim3((unsigned)(tiles << lg)), dim3(G::NT), G::LDS, s, a);
+            SVR2_LAUNCH_CHECK();
+            hipLaunchKernelGGL((conv_halo_finish_kernel<PW, BN>), dim3((unsigned)tiles), dim3(G::NT), G::EPI_BYTES, s, a);
+            SVR2_LAUNCH_CHECK();
+            return SVR2_OK;
+        }
+        a.ks_log2 = 0;
+        hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+    }
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
+}
+
+// Workspace a split conv of this shape would use (0: the shape is not split).
+template <int PW, int BN>
+size_t split_bytes(const KArgs& a) {
+    using G = GeoH<PW, BN>;
+    const long long tiles = (long long)a.cg.To * ((a.cg.Wo + PW - 1) / PW) * ((a.cg.Ho + G::PH - 1) / G::PH) * ((a.N + BN - 1) / BN);
+    const int lg = conv_halo_split(tiles, a.cg.kt * (a.cg.Cin / G::BK));
+    return lg > 0 ? (size_t)(tiles << lg) * G::BM * BN * 4 : 0;
 }
 
 }  // namespace
@@ -463,6 +552,14 @@ int conv_halo_launch(KArgs a, hipStream_t s) {
     // conv_out (Cout = 3): 1024-pixel x 16-channel tiles, 4x fewer MFMAs per pixel than a 128-channel tile
     if (a.N <= 16) return launch_halo<64, 16, false>(a, s);
     return (wr & 2) ? launch_halo<32, 128, true>(a, s) : launch_halo<32, 128, false>(a, s);
+}
+
+
+size_t conv_halo_split_bytes(const KArgs& a) {
+    const int wr = svr2::opt(svr2::OPT_HALO_WR, 3);
+    if (a.N % 256 == 0) return (wr & 1) ? split_bytes<16, 256>(a) : 0;
+    if (a.N <= 16) return 0;
+    return (wr & 2) ? split_bytes<32, 128>(a) : 0;
 }
 
 }  // namespace svr2

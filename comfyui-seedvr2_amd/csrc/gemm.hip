@@ -346,9 +346,9 @@ int launch(const KArgs& a, hipStream_t s) {
 namespace svr2 {
 static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
                                                  "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V",
-                                                 "SVR2_GEMM_DEEP", "SVR2_CONV_TFAST"};
+                                                 "SVR2_GEMM_DEEP", "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT"};
 static const int kUnset = INT32_MIN;
-static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
 static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
 
 int opt(Opt o, int dflt) {
@@ -461,6 +461,33 @@ extern "C" int32_t svr2_conv3d_gn_tiles(int32_t Ho, int32_t Wo, int32_t Cout) {
     return ((Ho + 15) / 16) * ((Wo + pw - 1) / pw);
 }
 
+static void conv_kargs(const svr2_conv3d_desc* d, KArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)d->x; a.W = (const bf16*)d->w; a.C = (bf16*)d->y;
+    a.bias = d->bias; a.resid = (const bf16*)d->resid; a.zero = (const bf16*)d->zero_page;
+    a.ldc = d->Cout; a.ldr = d->Cout;
+    a.M = (int)((long long)d->To * d->Ho * d->Wo); a.N = d->Cout; a.K = d->kt * d->kh * d->kw * d->Cin;
+    a.cg.carry = (const bf16*)d->carry;
+    a.cg.T = d->T; a.cg.Hi = d->Hi; a.cg.Wi = d->Wi; a.cg.Cin = d->Cin;
+    a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
+    a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
+    a.cg.To = d->To; a.cg.Ho = d->Ho; a.cg.Wo = d->Wo;
+}
+
+static bool conv_halo_shape(const svr2_conv3d_desc* d) {
+    return d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pad_h0 == 1 && d->pad_w0 == 1 &&
+           d->Ho == d->Hi && d->Wo == d->Wi;
+}
+
+extern "C" int64_t svr2_conv3d_split_ws_bytes(const svr2_conv3d_desc* d) {
+    if (!d || d->w_layout != SVR2_WL_TILED_128x32 || !conv_halo_shape(d) || d->Cin <= 0 || d->Cin % 32 || d->Cout <= 0 ||
+        d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || (long long)d->To * d->Ho * d->Wo >= (1ll << 31) - 256)
+        return 0;
+    KArgs a;
+    conv_kargs(d, a);
+    return (int64_t)conv_halo_split_bytes(a);
+}
+
 extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
     const bool tiled = d->w_layout == SVR2_WL_TILED_128x32;
@@ -485,21 +512,13 @@ extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     const long long M = (long long)d->To * d->Ho * d->Wo;
     SVR2_CHECK(M < (1ll << 31) - 256, SVR2_E_SHAPE, "svr2_conv3d: too many output pixels for one call");
     KArgs a;
-    memset(&a, 0, sizeof(a));
-    a.A = (const bf16*)d->x; a.W = (const bf16*)d->w; a.C = (bf16*)d->y;
-    a.bias = d->bias; a.resid = (const bf16*)d->resid; a.zero = (const bf16*)d->zero_page;
-    a.ldc = d->Cout; a.ldr = d->Cout;
-    a.M = (int)M; a.N = d->Cout; a.K = d->kt * d->kh * d->kw * d->Cin;
-    a.cg.carry = (const bf16*)d->carry;
-    a.cg.T = d->T; a.cg.Hi = d->Hi; a.cg.Wi = d->Wi; a.cg.Cin = d->Cin;
-    a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
-    a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
-    a.cg.To = d->To; a.cg.Ho = d->Ho; a.cg.Wo = d->Wo;
+    conv_kargs(d, a);
     if (tiled) {   // halo-resident kernel (conv_halo.hip): 3x3 spatial taps, stride 1, zero padding 1 on every side
-        const bool halo_shape = d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
-                                d->pad_h0 == 1 && d->pad_w0 == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
-        SVR2_CHECK(halo_shape, SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_TILED_128x32 needs a 3x3 stride-1 pad-1 conv");
+        SVR2_CHECK(conv_halo_shape(d), SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_TILED_128x32 needs a 3x3 stride-1 pad-1 conv");
+        SVR2_CHECK(!d->split_ws || aligned16(d->split_ws), SVR2_E_ALIGN, "svr2_conv3d: split_ws must be 16-byte aligned");
         a.stats = d->gn_partial;
+        a.partial = (float*)d->split_ws;
+        a.partial_bytes = d->split_ws ? (size_t)d->split_ws_bytes : 0;
         return conv_halo_launch(a, (hipStream_t)stream);
     }
     SVR2_CHECK(d->gn_partial == nullptr, SVR2_E_ARG, "svr2_conv3d: gn_partial needs w_layout SVR2_WL_TILED_128x32");

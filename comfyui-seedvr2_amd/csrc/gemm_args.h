@@ -22,6 +22,9 @@ struct KArgs {
     const bf16* resid;
     const bf16* zero;
     float* stats;                  // conv_halo.hip: per-tile per-channel (sum, sumsq) of the output, or null
+    float* partial;                // conv_halo.hip split-K: fp32 accumulator images [tile][split][32][512] x float4
+    int ks_log2;                   // ... log2 of the number of K splits (0 = no split)
+    size_t partial_bytes;          // ... capacity of `partial` (host side only)
     long long lda, ldc, ldr;
     int M, N, K, nbm, nbn;
     int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
@@ -34,9 +37,8 @@ constexpr int GROUP_M_TILES = 8;  // band height (in tiles) of the L2-friendly t
 // XCD-aware remap (bijective form): blocks b and b+8 share an XCD; give every XCD a contiguous run of the
 // tile order, and order tiles in bands of GROUP_M_TILES row-tiles so that the workgroups resident on one XCD
 // share A row-panels and W column-panels in its L2.
-__device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(const KArgs& a, int bid, int& tm, int& tn) {
     const int total = a.nbm * a.nbn;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, q = total >> 3, r = total & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int per_band = GROUP_M_TILES * a.nbn;
@@ -45,6 +47,7 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) {
     tm = band * GROUP_M_TILES + rem % rows;
     tn = rem / rows;
 }
+__device__ __forceinline__ void tile_coords(const KArgs& a, int& tm, int& tn) { tile_coords(a, blockIdx.x, tm, tn); }
 
 // Output row (pixel) index of row `row` of M-tile `tm`.  Conv tiles are 2-D pixel patches (BM/16 rows x 16
 // columns of one frame) so that a workgroup's nine spatial taps, and the ~64 workgroups resident on one
@@ -142,5 +145,6 @@ int gemm4_launch(int epi, KArgs a, hipStream_t s);
 int gemm2_launch(int amode, int epi, KArgs a, hipStream_t s);
 // implemented in conv_halo.hip: halo-resident stride-1 3x3(xkt) conv
 int conv_halo_launch(KArgs a, hipStream_t s);
+size_t conv_halo_split_bytes(const KArgs& a);
 
 }  // namespace svr2

@@ -17,6 +17,7 @@ Weights are taken in the reference's state-dict layout.
 
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from dataclasses import dataclass
@@ -149,6 +150,7 @@ class NaDiTHip:
             self.layers.append(L)
 
         self._rope7 = {}
+        self._txt_stream = None
         # rope tables (3B): angle = pos * theta^(-2i/42), i < 21  [ref: dit_3b/rope.py:74-85]
         nfreq = (cfg.head_dim // 3) // 2
         fr = 1.0 / (10000.0 ** (torch.arange(0, cfg.head_dim // 3, 2)[:nfreq].float() / (cfg.head_dim // 3)))
@@ -214,18 +216,29 @@ class NaDiTHip:
         return self._rope7[key]
 
     # ------------------------------------------------------------------ forward
-    def block(self, i: int, x: torch.Tensor, y: torch.Tensor, grid, taps=None):
+    def block(self, i: int, x: torch.Tensor, y: torch.Tensor, grid, taps=None, txt_lane=None):
+        """One MMDiT block.  txt_lane = (side stream, keep list): the text rows' norm / projections / MLP (58 rows: a
+        handful of workgroups per launch, latency-bound) are issued on the side stream and overlap the video rows' launches;
+        the two lanes meet at qkv_prep (needs both projections) and part again after txt_mean.  Every tensor that crosses
+        the lanes is parked in `keep` until the final join, so the caching allocator cannot hand its block out early."""
         cfg = self.cfg
         last = cfg.last_vid_only and i == cfg.num_layers - 1
         Lv, Lt_ = self.layers[i]["v"], self.layers[i]["t"]
         H, D, d = cfg.heads, cfg.head_dim, cfg.vid_dim
         ntxt = y.shape[0]
         pl = self._plan(grid, cfg.method(i), ntxt)
+        main = torch.cuda.current_stream(self.device)
+        side, keep = txt_lane if txt_lane is not None else (None, None)
+        lane = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         # attention half
+        with lane():
+            ya = hip.rmsnorm_mod(y, Lt_["attn_scale"], Lt_["attn_shift"], cfg.norm_eps)
+            qkv_t = hip.gemm(ya, Lt_["w_qkv"], 3 * H * D)
         xa = hip.rmsnorm_mod(x, Lv["attn_scale"], Lv["attn_shift"], cfg.norm_eps)
-        ya = hip.rmsnorm_mod(y, Lt_["attn_scale"], Lt_["attn_shift"], cfg.norm_eps)
         qkv_v = hip.gemm(xa, Lv["w_qkv"], 3 * H * D)
-        qkv_t = hip.gemm(ya, Lt_["w_qkv"], 3 * H * D)
+        if side is not None:
+            keep += [y, ya, qkv_t]
+            main.wait_stream(side)
         rc, rs = (self._rope_tables_7b(grid, cfg.method(i), ntxt) if cfg.rope_mode == 2
                   else (self.rope_cos, self.rope_sin))
         qkvw = hip.qkv_prep(qkv_v, qkv_t, pl["src_row"], pl["pos"], Lv["qn"], Lv["kn"], Lt_["qn"], Lt_["kn"],
@@ -246,25 +259,34 @@ class NaDiTHip:
             ot = hip.txt_mean(o2, pl["txt_row0"], ntxt)
             x1 = hip.gemm(o2, Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"], resid=x,
                           a_rows=pl["inv_rows"], m=x.shape[0])
-        y1 = hip.gemm(ot, Lt_["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lt_["b_out"], gate=Lt_["attn_gate"], resid=y)
+        if side is not None:
+            keep.append(ot)
+            side.wait_stream(main)
+        with lane():
+            y1 = hip.gemm(ot, Lt_["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lt_["b_out"], gate=Lt_["attn_gate"], resid=y)
         if taps is not None:
             taps["x1"] = x1; taps["y1"] = y1
         del o, o2
         # mlp half
-        def mlp(h_in, Lp, resid):
+        def mlp(h_in, Lp, resid, park=None):
             hn = hip.rmsnorm_mod(h_in, Lp["mlp_scale"], Lp["mlp_shift"], cfg.norm_eps)
             if cfg.mlp_type == "swiglu":
                 hmid = hip.gemm(hn, Lp["w_gi"], 2 * cfg.mlp_hidden, epilogue=hip.EPI_SWIGLU)
             else:
                 hmid = hip.gemm(hn, Lp["w_gi"], cfg.mlp_hidden, epilogue=hip.EPI_GELU, bias=Lp["b_gi"])
+            if park is not None:
+                park += [hn, hmid]
             return hip.gemm(hmid, Lp["w_mo"], d, epilogue=hip.EPI_GATE_RES, bias=Lp.get("b_mo"), gate=Lp["mlp_gate"],
                             resid=resid)
 
-        x2 = mlp(x1, Lv, x1)
         if not last:
-            y2 = mlp(y1, Lt_, y1)
+            with lane():
+                y2 = mlp(y1, Lt_, y1, keep)
+            if side is not None:
+                keep += [y1, y2]
         else:
             y2 = y1  # unused downstream
+        x2 = mlp(x1, Lv, x1)
         return x2, y2
 
     GRAPH_MAX_TOKENS = 32768   # below this the ~450 launches of a forward pass cost more than their kernels
@@ -326,10 +348,22 @@ class NaDiTHip:
         y = hip.gemm(txt, self.w_txt_in, cfg.vid_dim, bias=self.b_txt_in)
         if taps is not None:
             taps["x0"] = x; taps["y0"] = y
+        # small grids: the text rows run on a lane of their own (SVR2_DIT_TXT_LANE=0 disables, =1 forces)
+        lane_mode = os.environ.get("SVR2_DIT_TXT_LANE", "auto")
+        txt_lane = None
+        if lane_mode != "0" and (lane_mode == "1" or grid[0] * grid[1] * grid[2] <= self.GRAPH_MAX_TOKENS):
+            main = torch.cuda.current_stream(self.device)
+            if self._txt_stream is None:
+                self._txt_stream = torch.cuda.Stream(device=self.device)
+            txt_lane = (self._txt_stream, [])
+            self._txt_stream.wait_stream(main)
         for i in range(cfg.num_layers):
-            x, y = self.block(i, x, y, grid, taps if (taps is not None and i == 0) else None)
+            x, y = self.block(i, x, y, grid, taps if (taps is not None and i == 0) else None, txt_lane)
             if taps is not None:
                 taps[f"x{i + 1}"] = x
+        if txt_lane is not None:
+            main.wait_stream(self._txt_stream)      # the lanes join before anything parked in keep is released
+            txt_lane[1].clear()
         xo = hip.rmsnorm_mod(x, self.out_scale, self.out_shift, cfg.norm_eps) if cfg.out_norm else x
         pred = hip.gemm(xo, self.w_vid_out, cfg.vid_out_channels * 4, bias=self.b_vid_out)
         return hip.patch_out_x0(pred, noise)

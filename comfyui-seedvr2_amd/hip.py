@@ -49,6 +49,8 @@ class Conv3dDesc(C.Structure):
         ("zero_page", C.c_void_p),
         ("w_layout", C.c_int32),
         ("gn_partial", C.c_void_p),
+        ("split_ws", C.c_void_p),
+        ("split_ws_bytes", C.c_int64),
     ]
 
 
@@ -74,7 +76,7 @@ EXPORTS = [
     "svr2_abi_version", "svr2_last_error", "svr2_device_check", "svr2_set_option", "svr2_gemm", "svr2_conv3d", "svr2_im2col3d",
     "svr2_rmsnorm_mod", "svr2_qkv_prep", "svr2_window_attn", "svr2_window_attn_scatter", "svr2_txt_mean", "svr2_patch_in",
     "svr2_patch_out_x0", "svr2_groupnorm_ws_floats", "svr2_groupnorm_stats", "svr2_groupnorm_apply",
-    "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles",
+    "svr2_groupnorm_finalize", "svr2_conv3d_gn_tiles", "svr2_conv3d_split_ws_bytes",
     "svr2_attn_d512", "svr2_resize_pad_normalize", "svr2_resize_bicubic_aa", "svr2_blend_overlap", "svr2_crop_to_unit",
     "svr2_wavelet_level", "svr2_wavelet_merge", "svr2_adain_ws_bytes", "svr2_adain", "svr2_rgb_to_lab",
     "svr2_hist_match_ws_bytes", "svr2_hist_match", "svr2_lab_to_rgb",
@@ -343,6 +345,12 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
         part = GnPartial(torch.empty(To, tiles, 2, cout, dtype=torch.float32, device=x.device), tiles)
     d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out, w_layout,
                       part.buf if part is not None else None)
+    if w_layout == WL_TILED_128x32:      # scratch of the split-K path (small grids only; 0 bytes otherwise)
+        lib().svr2_conv3d_split_ws_bytes.restype = C.c_int64
+        nws = int(lib().svr2_conv3d_split_ws_bytes(C.byref(d)))
+        if nws > 0:
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+            d.split_ws, d.split_ws_bytes = _p(ws), nws
     _check(lib().svr2_conv3d(C.byref(d), _stream()), "svr2_conv3d")
     return (out, part) if gn_stats else out
 

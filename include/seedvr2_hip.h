@@ -129,9 +129,16 @@ typedef struct svr2_conv3d_desc {
     float* gn_partial;        /* optional (SVR2_WL_TILED_128x32 only): fp32 [To][tiles][2][Cout] per-tile per-channel
                                  (sum, sum of squares) of the bf16 outputs, tiles = svr2_conv3d_gn_tiles(Ho, Wo, Cout);
                                  feeds svr2_groupnorm_finalize so the following GroupNorm needs no statistics pass */
+    void* split_ws;           /* optional (SVR2_WL_TILED_128x32 only): >= svr2_conv3d_split_ws_bytes(d) bytes of scratch, 16-byte */
+    int64_t split_ws_bytes;   /* aligned.  With it, a conv whose grid would leave most of the chip idle (latent-resolution
+                                 512-channel convs of a small image: 16-128 tiles, 48 channel slices) is split 2-8 ways along
+                                 K; a second launch adds the fp32 partial tiles in a fixed order and finishes them.  NULL or
+                                 too small: never split.  Split and unsplit results differ by fp32 summation order only. */
 } svr2_conv3d_desc;
 
 int svr2_conv3d(const svr2_conv3d_desc* d, void* stream);
+/* Scratch bytes svr2_conv3d would use for this descriptor (pointers are not read); 0 = this shape is not split. */
+int64_t svr2_conv3d_split_ws_bytes(const svr2_conv3d_desc* d);
 int32_t svr2_conv3d_gn_tiles(int32_t Ho, int32_t Wo, int32_t Cout);
 
 /* Explicit im2col for the small-Cin causal convs (Cin = 3 or 16): col[M, kpad] with

@@ -211,6 +211,50 @@ def test_conv3d_halo_resident(pkg, gpu, case, wr, lib_option):
         assert_close(out, out0.float().cpu(), f"conv3d halo vs tap-staged {case}")
 
 
+@pytest.mark.parametrize("case", [
+    (1, 64, 64, 512, 512, 3, False, True),     # the latent-resolution convs of a 512 x 512 image: 32 tiles -> 8 splits
+    (2, 40, 56, 256, 256, 3, True, True),      # ragged patches, carried head, residual: 24 tiles, 24 slices -> 4 splits
+    (1, 72, 80, 128, 128, 3, False, False),    # <32,128> geometry, 12 slices -> 2 splits
+    (1, 48, 48, 384, 256, 1, False, True),     # kt = 1 (12 slices)
+])
+def test_conv3d_split_k(pkg, gpu, case, lib_option):
+    """Split-K path of the halo conv (small grids): against torch, against the unsplit kernel (fp32 summation order is
+    the only difference: a few outputs move by one bf16 ulp), GroupNorm partial sums included; and the workspace query."""
+    hip = pkg.hip
+    T, H, W, Cin, Cout, kt, with_carry, with_res = case
+    k, s, npad, pad_hw = (kt, 3, 3), (1, 1, 1), kt - 1, (1, 1, 1, 1)
+    x = rnd(T, H, W, Cin, seed=125)
+    w = rnd(Cout, *k, Cin, seed=126, scale=1 / math.sqrt(Cin * 9 * kt))
+    b = rnd(Cout, seed=127)
+    carry = rnd(npad, H, W, Cin, seed=128) if (with_carry and npad) else None
+    ref = conv_ref(x, w, b, k, s, npad, pad_hw, carry)
+    res = rnd(*ref.shape, seed=129) if with_res else None
+    if with_res:
+        ref = ref + res
+    wt = hip.conv_weight_tiled(w.permute(0, 4, 1, 2, 3).to(gpu))
+    kw = dict(npad=npad, pad_hw=pad_hw, carry=None if carry is None else dev_bf16(carry, gpu), bias=b.to(gpu),
+              resid=None if res is None else dev_bf16(res, gpu), w_layout=hip.WL_TILED_128x32, gn_stats=True)
+    outs = {}
+    for split in (0, 1):
+        lib_option("SVR2_CONV_SPLIT", split)
+        d, _ = hip._conv_desc(dev_bf16(x, gpu), wt, Cout, k, s, npad, pad_hw, None, None, None, None, hip.WL_TILED_128x32, None)
+        hip.lib().svr2_conv3d_split_ws_bytes.restype = hip.C.c_int64
+        nws = int(hip.lib().svr2_conv3d_split_ws_bytes(hip.C.byref(d)))
+        assert (nws > 0) == bool(split), (split, nws)
+        out, part = hip.conv3d(dev_bf16(x, gpu), wt, Cout, k, s, **kw)
+        torch.cuda.synchronize()
+        assert_close(out, ref, f"conv3d split={split} {case}")
+        outs[split] = (out.float().cpu(), part.buf.float().cpu())
+    a, bb = outs[0][0], outs[1][0]
+    diff = (a - bb).abs()
+    assert (diff > 0).float().mean() < 0.02, (diff > 0).float().mean()
+    # one bf16 ulp of the conv value (rounded before the residual is added) plus one of the rounded sum
+    mag = a.abs() + (res.abs() if with_res else 0)
+    assert (diff <= (mag + a.abs()) * 2 ** -7 + 1e-6).all()
+    pa, pb = outs[0][1], outs[1][1]
+    assert pa.shape == pb.shape and torch.allclose(pa, pb, rtol=2e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("Cin,with_carry", [(3, False), (16, True)])
 def test_im2col_gemm_small_cin(pkg, gpu, Cin, with_carry):
     hip = pkg.hip
@@ -386,6 +430,41 @@ def test_dit_graph_replay_equals_eager(pkg, gpu, monkeypatch):
     assert not torch.equal(outs["1"][0][0], outs["1"][0][1])
     print(f"DiT forward (4 layers, 72 tokens): eager {outs['0'][1]*1e3:.2f} ms, graph replay {outs['1'][1]*1e3:.2f} ms")
     assert len(model._graphs) == 1
+
+
+@pytest.mark.parametrize("flavour", ["3b", "7b"])
+def test_dit_txt_lane_equals_single_stream(pkg, gpu, monkeypatch, flavour):
+    """The text rows' launches on a side stream (dit.block txt_lane): same bits as the single-stream order, eager and
+    under graph capture, for fresh inputs on every call (a lane that read a buffer too early would show here)."""
+    from seedvr2_ref import dit as odit
+    kw = dict(vid_dim=256, heads=2, head_dim=128, num_layers=5, mm_layers=2, txt_in_dim=64, mlp_multiple_of=64)
+    if flavour == "7b":
+        kw.update(mm_layers=5, mlp_type="normal", out_norm=False, last_vid_only=False)
+    dcfg = odit.DiTConfig(**kw)
+    dp = {k: v.to(torch.bfloat16).float() for k, v in odit.synthetic_params(dcfg, 8).items()}
+    model = pkg.dit.NaDiTHip(pkg.dit.DiTConfig(rope_mode=1 if flavour == "3b" else 2, **kw), dp, gpu)
+    g = torch.Generator().manual_seed(16)
+    txt = torch.randn(58, 64, generator=g).to(torch.bfloat16).to(gpu)
+    outs = {}
+    for lane in ("0", "1"):
+        for graph in ("0", "1"):
+            monkeypatch.setenv("SVR2_DIT_TXT_LANE", lane)
+            monkeypatch.setenv("SVR2_DIT_GRAPH", graph)
+            if hasattr(model, "_graphs"):
+                model._graphs.clear()
+            res = []
+            for seed in (1, 2, 3, 4):
+                gg = torch.Generator().manual_seed(seed)
+                noise = torch.randn(5, 16, 24, 16, generator=gg).to(torch.bfloat16).to(gpu)
+                lat = torch.randn(5, 16, 24, 16, generator=gg).to(torch.bfloat16).to(gpu)
+                res.append(model.one_step(noise, lat, txt).clone())
+            torch.cuda.synchronize()
+            outs[(lane, graph)] = res
+    ref = outs[("0", "0")]
+    assert not torch.equal(ref[0], ref[1])
+    for key, res in outs.items():
+        for a, b in zip(ref, res):
+            assert torch.equal(a, b), key
 
 
 @pytest.mark.parametrize("grid_thw", [(2, 16, 24), (3, 20, 36)])
