@@ -445,8 +445,25 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
 }
 
-// Second launch of a split conv: one workgroup per tile adds the S accumulator images in split order and finishes the
-// tile exactly like the unsplit kernel does (bias, bf16 rounding, residual, GroupNorm partial sums).
+// Split convs with many images per tile (S >= 4): the images are added by the whole chip first (one float4 per thread,
+// split order, into image 0) - 32 finishing workgroups reading 8 x 256 KiB each took as long as the multiplication.
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(f32x4* img, long long n4, int per_tile4, int ks_log2) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    const long long tile = e / per_tile4;
+    f32x4* p = img + ((tile << ks_log2) * per_tile4) + (e - tile * per_tile4);
+    f32x4 s = p[0];
+    for (int k = 1; k < (1 << ks_log2); ++k) {
+        const f32x4 v = p[(long long)k * per_tile4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+    p[0] = s;
+}
+
+// Last launch of a split conv: one workgroup per tile adds the accumulator images that are still separate (a.nsum of
+// them, split order) and finishes the tile exactly like the unsplit kernel does (bias, bf16 rounding, residual,
+// GroupNorm partial sums).
 template <int PW, int BN>
 __global__ __launch_bounds__(512, 2) void conv_halo_finish_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_finish_kernel(const KArgs a)
     const int wpx0 = wm * 16;
     const int frow = lane & 15, fq = lane >> 4;
     const int pix = frow < 4 ? 2 * frow : (frow < 12 ? 2 * frow - 7 : 2 * frow - 16);
-    const int S = 1 << a.ks_log2;
+    const int S = a.nsum;
     const f32x4* img = (const f32x4*)a.partial + (((long long)(tm * a.nbn + tn)) << a.ks_log2) * (MI * JN * G::NT) + tid;
     f32x4 acc[MI][JN];
 #pragma unroll
@@ -516,6 +533,15 @@ int launch_halo(KArgs a, hipStream_t s) {
             a.ks_log2 = lg;
             hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, true>), dim3((unsigned)(tiles << lg)), dim3(G::NT), G::LDS, s, a);
             SVR2_LAUNCH_CHECK();
+            a.nsum = 1 << lg;
+            if (lg >= 2) {
+                const int per_tile4 = G::BM * BN / 4;
+                const long long n4 = tiles * per_tile4;
+                hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                                   (f32x4*)a.partial, n4, per_tile4, lg);
+                SVR2_LAUNCH_CHECK();
+                a.nsum = 1;
+            }
             hipLaunchKernelGGL((conv_halo_finish_kernel<PW, BN>), dim3((unsigned)tiles), dim3(G::NT), G::EPI_BYTES, s, a);
             SVR2_LAUNCH_CHECK();
             return SVR2_OK;

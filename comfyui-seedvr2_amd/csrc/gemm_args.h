@@ -24,6 +24,7 @@ struct KArgs {
     float* stats;                  // conv_halo.hip: per-tile per-channel (sum, sumsq) of the output, or null
     float* partial;                // conv_halo.hip split-K: fp32 accumulator images [tile][split][32][512] x float4
     int ks_log2;                   // ... log2 of the number of K splits (0 = no split)
+    int nsum;                      // ... images per tile the finishing kernel still has to add
     size_t partial_bytes;          // ... capacity of `partial` (host side only)
     long long lda, ldc, ldr;
     int M, N, K, nbm, nbn;
