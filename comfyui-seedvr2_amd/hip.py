@@ -533,6 +533,26 @@ def attn_d512(qkv: torch.Tensor, frames: int, tokens: int, out: Optional[torch.T
     return out
 
 
+class ResizeTaps(tuple):
+    """(wy, ymin, ycnt, wx, xmin, xcnt) device tables plus `bounds` = (max(ymin+ycnt), max(xmin+xcnt), max(ycnt), max(xcnt))
+    taken on the host when the tables were built, so the wrappers can check them against the input size without a device
+    reduction (and the host synchronisation that reading one back costs on every call)."""
+
+    def __new__(cls, tables, bounds):
+        obj = super().__new__(cls, tables)
+        obj.bounds = tuple(int(b) for b in bounds)
+        return obj
+
+
+def _taps_bounds(taps):
+    b = getattr(taps, "bounds", None)
+    if b is None or os.environ.get("SVR2_TAPS_SYNC") == "1":   # plain tuple from an outside caller (or the A/B switch):
+        # reduce on the device -- this synchronises the host with the stream
+        _, ymin, ycnt, _, xmin, xcnt = taps
+        b = (int((ymin + ycnt).max()), int((xmin + xcnt).max()), int(ycnt.max()), int(xcnt.max()))
+    return b
+
+
 def resize_pad_normalize(frames: torch.Tensor, taps, hp: int, wp: int) -> torch.Tensor:
     """frames bf16 [T,Hin,Win,3] in [0,1] -> bf16 [T,hp,wp,3] model input; taps from pipeline.resize_taps()."""
     _bf16c(frames, "resize.frames")
@@ -542,7 +562,8 @@ def resize_pad_normalize(frames: torch.Tensor, taps, hp: int, wp: int) -> torch.
     wy, ymin, ycnt, wx, xmin, xcnt = taps
     Hout, KY = wy.shape
     Wout, KX = wx.shape
-    if int((ymin + ycnt).max()) > Hin or int((xmin + xcnt).max()) > Win or int(ycnt.max()) > KY or int(xcnt.max()) > KX:
+    ymax, xmax, kymax, kxmax = _taps_bounds(taps)
+    if ymax > Hin or xmax > Win or kymax > KY or kxmax > KX:
         raise HipError("resize: tap table reaches outside the input")
     if hp < Hout or wp < Wout:
         raise HipError("resize: padded size smaller than the resized image")
@@ -563,7 +584,8 @@ def resize_bicubic_aa(frames: torch.Tensor, taps) -> torch.Tensor:
     wy, ymin, ycnt, wx, xmin, xcnt = taps
     Hout, KY = wy.shape
     Wout, KX = wx.shape
-    if int((ymin + ycnt).max()) > Hin or int((xmin + xcnt).max()) > Win or int(ycnt.max()) > KY or int(xcnt.max()) > KX:
+    ymax, xmax, kymax, kxmax = _taps_bounds(taps)
+    if ymax > Hin or xmax > Win or kymax > KY or kxmax > KX:
         raise HipError("resize: tap table reaches outside the input")
     out = torch.empty(T, Hout, Wout, 3, dtype=torch.bfloat16, device=frames.device)
     _check(lib().svr2_resize_bicubic_aa(_p(frames), _p(out), _p(wy), _p(ymin), _p(ycnt), _p(wx), _p(xmin), _p(xcnt),

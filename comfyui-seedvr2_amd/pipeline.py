@@ -162,7 +162,8 @@ class SeedVR2Pipeline:
             wy, ymin, ycnt = aa_bicubic_taps(hin, rh)
             wx, xmin, xcnt = aa_bicubic_taps(win, rw)
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-            self._taps[key] = tuple(up(a) for a in (wy, ymin, ycnt, wx, xmin, xcnt))
+            bounds = (int((ymin + ycnt).max()), int((xmin + xcnt).max()), int(ycnt.max()), int(xcnt.max()))
+            self._taps[key] = hip.ResizeTaps((up(a) for a in (wy, ymin, ycnt, wx, xmin, xcnt)), bounds)
         return self._taps[key]
 
     # one batch, device resident ------------------------------------------------------------
@@ -227,20 +228,31 @@ class SeedVR2Pipeline:
             bf_ = input_noise_scale * 0.5
             x = hip.noise_mix(x, nz, 1 - bf_, bf_, 0)
             del nz
-        latent = self.vae.encode(x, **self.encode_tiling)
-        del x
+        # The noise has the latent's shape, which follows from x: draw it (CPU generator, like the reference's CPU path) and
+        # start its upload BEFORE the encoder is enqueued.  Issued after it, the copy reached the GPU 0.76 ms after the
+        # encoder's last kernel on a 512 x 512 image (the host draw of 65 k bf16 numbers alone takes 0.9 ms).  Page-locked
+        # source + non_blocking: the host never waits for the stream.
+        vcfg = self.vae.cfg
+        sdown, tdown = 2 ** (len(vcfg.block_out_channels) - 1), 2 ** vcfg.temporal_scale_num
+        lshape = ((x.shape[0] - 1) // tdown + 1, x.shape[1] // sdown, x.shape[2] // sdown, vcfg.latent_channels)
         second = None
         if noise is None:
             g = torch.Generator(device="cpu").manual_seed(int(seed))
-            noise = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16, device="cpu")
+            noise = torch.randn(lshape, generator=g, dtype=torch.bfloat16, device="cpu", pin_memory=True)
             if latent_noise_scale > 0:
-                second = torch.randn(tuple(latent.shape), generator=g, dtype=torch.bfloat16, device="cpu")
+                second = torch.randn(lshape, generator=g, dtype=torch.bfloat16, device="cpu", pin_memory=True)
         elif latent_noise_scale > 0:
             raise hip.HipError("latent_noise_scale needs the pipeline's own noise (base and aug noise share a generator)")
-        noise = noise.to(self.device).contiguous()
+        noise = noise.to(self.device, non_blocking=True).contiguous()
+        if second is not None:
+            second = second.to(self.device, non_blocking=True).contiguous()
+        latent = self.vae.encode(x, **self.encode_tiling)
+        del x
+        if tuple(latent.shape) != tuple(noise.shape):
+            raise hip.HipError(f"noise shape {tuple(noise.shape)} does not match the latent {tuple(latent.shape)}")
         cond = latent
         if latent_noise_scale > 0:
-            aug = hip.noise_mix(noise, second.to(self.device).contiguous(), 0.1, 0.05, 1)
+            aug = hip.noise_mix(noise, second, 0.1, 0.05, 1)
             a_, b_ = self.blur_coefficients(latent.shape, latent_noise_scale)
             cond = hip.noise_mix(latent, aug, a_, b_, 2)
             del aug
