@@ -51,3 +51,37 @@ with torch.cuda.device(dev):
         print(f"-- image {rep}: GPU done after {1e3 * (t1 - t0):.2f} ms; host:")
         for n, t in marks:
             print(f"   {1e3 * (t - t0):8.2f} ms  {n}")
+
+# ---- host duration of every hip.* call inside the mid-block attention (free-running loop, no synchronisation)
+import collections
+durs = collections.defaultdict(list)
+def timed(name, fn):
+    def inner(*a, **k):
+        t = time.perf_counter(); r = fn(*a, **k); durs[name].append(1e6 * (time.perf_counter() - t)); return r
+    return inner
+vae.encode, vae.decode, dit.one_step = orig_enc, orig_dec, orig_step
+orig_mid = vae._mid_attention
+state = {"on": False}
+for nm in ("groupnorm_silu", "gemm", "attn_d512"):
+    f = getattr(hip, nm)
+    def mk(nm, f):
+        def inner(*a, **k):
+            if not state["on"]:
+                return f(*a, **k)
+            t = time.perf_counter(); r = f(*a, **k); durs[nm].append(1e6 * (time.perf_counter() - t)); return r
+        return inner
+    setattr(hip, nm, mk(nm, f))
+pkg.vae.hip = hip
+def mid(*a, **k):
+    state["on"] = True
+    t = time.perf_counter(); r = orig_mid(*a, **k); durs["_mid_attention total"].append(1e6 * (time.perf_counter() - t))
+    state["on"] = False
+    return r
+vae._mid_attention = mid
+with torch.cuda.device(dev):
+    for _ in range(20):
+        pipe.upscale_batch(lr, 512, 42)
+    torch.cuda.synchronize()
+for k, v in durs.items():
+    v = sorted(v)
+    print(f"host us per call  {k:24s} n={len(v):4d} median {v[len(v)//2]:7.1f}  max {v[-1]:7.1f}")

@@ -20,6 +20,14 @@ for i, (s, e, n) in enumerate(tail[1:], 1):
     if s - cur_e > best[0]:
         best = (s - cur_e, i)
     cur_e = max(cur_e, e)
+if len(sys.argv) > 2:      # context of every event whose name contains argv[2] instead of the largest gap
+    for j, (s, e, n) in enumerate(tail):
+        if sys.argv[2] in n:
+            t0 = tail[max(0, j - 12)][0]
+            print(f"-- context of event {j}")
+            for s2, e2, n2 in tail[max(0, j - 12): j + 5]:
+                print(f"  +{(s2 - t0) / 1e3:9.1f} us  dur {(e2 - s2) / 1e3:8.1f} us  {n2}")
+    sys.exit(0)
 g, i = best
 print(f"largest gap in the last 30 ms: {g / 1e3:.1f} us before event {i}")
 t0 = tail[max(0, i - 8)][0]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU idle time from a rocprofv3 --kernel-trace CSV: union of the kernels' [start, end) intervals against the span they
 cover (kernels on different streams overlap, so the union, not the sum, is the busy time), and where the gaps are.
-  usage: tools/gpu_idle.py <..._kernel_trace.csv> [skip_fraction]   (skip the first fraction of the span: model build, warm-up)"""
+  usage: tools/gpu_idle.py <..._kernel_trace.csv> [skip_fraction [stop_fraction]]   (analyse that window of the span)"""
 import csv
 import sys
 
@@ -9,13 +9,15 @@ import sys
 def main():
     path = sys.argv[1]
     skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    stop = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     ev = []
     for r in csv.DictReader(open(path)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
     ev.sort()
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     cut = t0 + int((t1 - t0) * skip)
-    ev = [e for e in ev if e[0] >= cut]
+    end = t0 + int((t1 - t0) * stop)
+    ev = [e for e in ev if cut <= e[0] < end]
     busy, cur_s, cur_e = 0, ev[0][0], ev[0][1]
     gaps, pairs, prev = [], [], ev[0][2]
     for s, e, n in ev[1:]:
