@@ -232,9 +232,14 @@ class SeedVR2Pipeline:
         # start its upload BEFORE the encoder is enqueued.  Issued after it, the copy reached the GPU 0.76 ms after the
         # encoder's last kernel on a 512 x 512 image (the host draw of 65 k bf16 numbers alone takes 0.9 ms).  Page-locked
         # source + non_blocking: the host never waits for the stream.
-        vcfg = self.vae.cfg
-        sdown, tdown = 2 ** (len(vcfg.block_out_channels) - 1), 2 ** vcfg.temporal_scale_num
-        lshape = ((x.shape[0] - 1) // tdown + 1, x.shape[1] // sdown, x.shape[2] // sdown, vcfg.latent_channels)
+        vcfg = getattr(self.vae, "cfg", None)
+        latent = None
+        if vcfg is not None:
+            sdown, tdown = 2 ** (len(vcfg.block_out_channels) - 1), 2 ** vcfg.temporal_scale_num
+            lshape = ((x.shape[0] - 1) // tdown + 1, x.shape[1] // sdown, x.shape[2] // sdown, vcfg.latent_channels)
+        else:           # a codec that does not describe its strides: its latent tells the shape (noise drawn after the encode)
+            latent = self.vae.encode(x, **self.encode_tiling)
+            lshape = tuple(latent.shape)
         second = None
         if noise is None:
             g = torch.Generator(device="cpu").manual_seed(int(seed))
@@ -246,7 +251,8 @@ class SeedVR2Pipeline:
         noise = noise.to(self.device, non_blocking=True).contiguous()
         if second is not None:
             second = second.to(self.device, non_blocking=True).contiguous()
-        latent = self.vae.encode(x, **self.encode_tiling)
+        if latent is None:
+            latent = self.vae.encode(x, **self.encode_tiling)
         del x
         if tuple(latent.shape) != tuple(noise.shape):
             raise hip.HipError(f"noise shape {tuple(noise.shape)} does not match the latent {tuple(latent.shape)}")
