@@ -185,6 +185,14 @@ if __name__ == "__main__":
         bench_gemm(M, 2560, 2560, "gate", gather=True)
         bench_gemm(M, 13824, 2560, "swiglu")
         bench_gemm(M, 2560, 6912, "gate")
+    if "gemmrounds" in which:   # one, four and many rounds of 256 x 256 tiles on 256 CUs: how much of gemm4's DMA cost is
+        # lost L2 sharing between workgroups that drift apart in time (first round: every sharer starts together)
+        bench_gemm(8192, 2048, 2560)
+        bench_gemm(16384, 2048, 2560)
+        bench_gemm(16384, 4096, 2560)
+        bench_gemm(32768, 4096, 2560)
+        bench_gemm(65536, 7680, 2560)
+        bench_gemm(194400, 7680, 2560)
     if "gemmsmall" in which:   # the memory-bound / narrow GEMMs of the VAE (run once per SVR2_GEMM_V value)
         print("SVR2_GEMM_V =", os.environ.get("SVR2_GEMM_V", "2"))
         bench_gemm(33177600, 128, 128)        # encoder conv_in after im2col, 4 frames at 4K
