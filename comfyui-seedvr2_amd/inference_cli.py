@@ -279,6 +279,8 @@ def main(argv=None, runtime: Runtime = None) -> int:
                 dist.init_process_group(backend="nccl", device_id=torch.device(dev))
             else:
                 dist.init_process_group(backend=rt.dist_backend)
+        if a.model_dir:     # --model_dir is where the DiT, VAE and text-embedding files live [ref: inference_cli.py:835-844]
+            os.environ["SEEDVR2_MODEL_DIR"] = a.model_dir
         dit_cfg, = pkg.nodes.SeedVR2LoadDiTModel.execute(model=a.dit_model, device=dev)
         vae_cfg, = pkg.nodes.SeedVR2LoadVAEModel.execute(
             device=dev, encode_tiled=a.vae_encode_tiled, encode_tile_size=a.vae_encode_tile_size,

@@ -342,7 +342,7 @@ def test_cli_from_checkpoint_files(pkg, gpu, tmp_path, monkeypatch):
     lr = torch.rand(1, 24, 32, 3, generator=torch.Generator().manual_seed(34))
     lr = (lr * 255).round() / 255
     torch.save(lr, str(tmp_path / "in.pt"))
-    monkeypatch.setenv("SEEDVR2_MODEL_DIR", str(mdir))
+    monkeypatch.delenv("SEEDVR2_MODEL_DIR", raising=False)      # --model_dir alone must be enough
     out_path = str(tmp_path / "out.npy")
     import importlib
     cli = importlib.import_module(pkg.__name__ + ".inference_cli")
