@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off parity run at BASELINE configs[1]'s TRUE size: [8,540,960,3] -> 1080p, batch_size 9 (4n+1 padding), seed 42,
+"""One-off parity runs at TRUE sizes (default BASELINE configs[1]: [8,540,960,3] -> 1080p, batch_size 9 (4n+1 padding), seed 42;
+`1 720 1280 2160 1 4k_frame` = one 4K frame through the kernels' 4K shapes),
 NaDiT-3B + full VAE on synthetic weights; HIP path vs the bf16 oracle (and the fp32 oracle if the time limit allows) on the
 box's host threads.  Test infrastructure (it runs the oracle), too slow for the collected suite (the oracle needs minutes); writes gpurun_out/parity_cfg2_fullsize.json."""
 import json
@@ -20,7 +21,10 @@ from tests_support import psnr
 pkg = ge.load_package()
 from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
 
-OUT = os.path.join(ROOT, "gpurun_out", "parity_cfg2_fullsize.json")
+# argv: frames hin win resolution batch_size tag   (default: configs[1])
+NFR, HIN, WIN, RES, BSZ = (int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 540, 960, 1080, 9)))
+TAG = sys.argv[6] if len(sys.argv) > 6 else "cfg2_fullsize"
+OUT = os.path.join(ROOT, "gpurun_out", f"parity_{TAG}.json")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 t_start = time.time()
 stop = False
@@ -28,7 +32,7 @@ stop = False
 
 def heartbeat():
     while not stop:
-        with open(os.path.join(ROOT, "gpurun_out", "parity_cfg2_heartbeat.txt"), "w") as fh:
+        with open(os.path.join(ROOT, "gpurun_out", f"parity_{TAG}_heartbeat.txt"), "w") as fh:
             fh.write(f"{time.time() - t_start:.0f}s\n")
         print(f"[heartbeat] {time.time() - t_start:.0f}s", flush=True)
         time.sleep(45)
@@ -48,14 +52,14 @@ del vsd, dsd
 txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).float()
 pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, dev)
 g = torch.Generator().manual_seed(1234)
-low = 0.5 + 0.2 * torch.randn(8, 3, 34, 60, generator=g)
-lr = torch.nn.functional.interpolate(low, size=(540, 960), mode="bicubic", align_corners=False).clamp(0, 1)
+low = 0.5 + 0.2 * torch.randn(NFR, 3, max(HIN // 16, 2), max(WIN // 16, 2), generator=g)
+lr = torch.nn.functional.interpolate(low, size=(HIN, WIN), mode="bicubic", align_corners=False).clamp(0, 1)
 lr = ((lr * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
 
 t0 = time.time()
-got = pipe.generate(lr, resolution=1080, batch_size=9, temporal_overlap=0, seed=42, color_correction="none").float().cpu()
+got = pipe.generate(lr, resolution=RES, batch_size=BSZ, temporal_overlap=0, seed=42, color_correction="none").float().cpu()
 torch.cuda.synchronize()
-row = {"input": "[8,540,960,3] -> 1080p, batch_size 9, seed 42, color_correction none, NaDiT-3B + VAE 128/256/512/512",
+row = {"input": f"[{NFR},{HIN},{WIN},3] -> {RES}p, batch_size {BSZ}, seed 42, color_correction none, NaDiT-3B + VAE 128/256/512/512",
        "hip_seconds": time.time() - t0, "shape": list(got.shape), "cpu_threads": torch.get_num_threads()}
 print(row, flush=True)
 refs = {}
@@ -65,7 +69,7 @@ for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
         row["fp32"] = "skipped: time limit"
         break
     t0 = time.time()
-    refs[name] = opipe.generate(lr, vp, vcfg_o, dp, odit.CFG_3B, txt, 1080, 9, 0, 42, dt, rope_mode="3b").float()
+    refs[name] = opipe.generate(lr, vp, vcfg_o, dp, odit.CFG_3B, txt, RES, BSZ, 0, 42, dt, rope_mode="3b").float()
     row[f"oracle_{name}_seconds"] = time.time() - t0
     row[f"psnr_hip_vs_{name}oracle"] = psnr(got, refs[name])
     row[f"maxabs_hip_vs_{name}oracle"] = (got - refs[name]).abs().max().item()
