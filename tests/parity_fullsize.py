@@ -21,9 +21,10 @@ from tests_support import psnr
 pkg = ge.load_package()
 from seedvr2_ref import dit as odit, pipeline as opipe, vae as ovae
 
-# argv: frames hin win resolution batch_size tag   (default: configs[1])
+# argv: frames hin win resolution batch_size tag [3b|7b]   (default: configs[1], 3B)
 NFR, HIN, WIN, RES, BSZ = (int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 540, 960, 1080, 9)))
 TAG = sys.argv[6] if len(sys.argv) > 6 else "cfg2_fullsize"
+MODEL = sys.argv[7] if len(sys.argv) > 7 else "3b"
 OUT = os.path.join(ROOT, "gpurun_out", f"parity_{TAG}.json")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 t_start = time.time()
@@ -43,9 +44,11 @@ torch.set_num_threads(min(os.cpu_count() or 1, 64))
 dev = torch.device("cuda:0")
 vcfg_h, vcfg_o = pkg.vae.VAEConfig(), ovae.VAEConfig()
 vsd = pkg.vae.synthetic_state_dict(vcfg_h, dev, seed=1)
-dsd = pkg.dit.synthetic_state_dict(pkg.dit.CFG_3B, dev, seed=2)
+DCFG_H = pkg.dit.CFG_7B if MODEL == "7b" else pkg.dit.CFG_3B
+DCFG_O = odit.CFG_7B if MODEL == "7b" else odit.CFG_3B
+dsd = pkg.dit.synthetic_state_dict(DCFG_H, dev, seed=2)
 vae = pkg.vae.VideoVAEHip(vcfg_h, vsd, dev)
-dit = pkg.dit.NaDiTHip(pkg.dit.CFG_3B, dsd, dev)
+dit = pkg.dit.NaDiTHip(DCFG_H, dsd, dev)
 vp = {k: v.detach().cpu() for k, v in vsd.items()}
 dp = {k: v.detach().cpu() for k, v in dsd.items()}
 del vsd, dsd
@@ -59,7 +62,7 @@ lr = ((lr * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
 t0 = time.time()
 got = pipe.generate(lr, resolution=RES, batch_size=BSZ, temporal_overlap=0, seed=42, color_correction="none").float().cpu()
 torch.cuda.synchronize()
-row = {"input": f"[{NFR},{HIN},{WIN},3] -> {RES}p, batch_size {BSZ}, seed 42, color_correction none, NaDiT-3B + VAE 128/256/512/512",
+row = {"input": f"[{NFR},{HIN},{WIN},3] -> {RES}p, batch_size {BSZ}, seed 42, color_correction none, NaDiT-{MODEL} + VAE 128/256/512/512",
        "hip_seconds": time.time() - t0, "shape": list(got.shape), "cpu_threads": torch.get_num_threads()}
 print(row, flush=True)
 refs = {}
@@ -69,7 +72,7 @@ for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
         row["fp32"] = "skipped: time limit"
         break
     t0 = time.time()
-    refs[name] = opipe.generate(lr, vp, vcfg_o, dp, odit.CFG_3B, txt, RES, BSZ, 0, 42, dt, rope_mode="3b").float()
+    refs[name] = opipe.generate(lr, vp, vcfg_o, dp, DCFG_O, txt, RES, BSZ, 0, 42, dt, rope_mode=MODEL).float()
     row[f"oracle_{name}_seconds"] = time.time() - t0
     row[f"psnr_hip_vs_{name}oracle"] = psnr(got, refs[name])
     row[f"maxabs_hip_vs_{name}oracle"] = (got - refs[name]).abs().max().item()
