@@ -32,6 +32,20 @@ def test_resize_taps_match_aten_antialias_bicubic(pkg, hin, win, res):
     assert (got - ref).abs().max() < 2e-5
 
 
+def test_resize_taps_carry_host_side_bounds(pkg):
+    """The tap tables travel with the maxima the resize wrappers check against the input size (hip.ResizeTaps), taken on
+    the host when the tables are built: reading them back from the device on every call would synchronise every batch."""
+    import numpy as np
+    import torch
+    wy, ymin, ycnt = pkg.pipeline.aa_bicubic_taps(37, 90)
+    wx, xmin, xcnt = pkg.pipeline.aa_bicubic_taps(53, 40)
+    bounds = (int((ymin + ycnt).max()), int((xmin + xcnt).max()), int(ycnt.max()), int(xcnt.max()))
+    taps = pkg.hip.ResizeTaps((torch.from_numpy(np.ascontiguousarray(a)) for a in (wy, ymin, ycnt, wx, xmin, xcnt)), bounds)
+    assert len(taps) == 6 and taps.bounds == bounds and pkg.hip._taps_bounds(taps) == bounds
+    assert bounds[0] <= 37 and bounds[1] <= 53 and bounds[2] <= wy.shape[1] and bounds[3] <= wx.shape[1]
+    assert pkg.hip._taps_bounds(tuple(taps)) == bounds          # a plain tuple falls back to reducing the tables
+
+
 def test_target_dims_and_oracle_agree(pkg):
     from seedvr2_ref import pipeline as opipe
     for (h, w, r) in [(720, 1280, 2160), (540, 960, 1080), (256, 256, 512), (1280, 720, 1080), (101, 57, 90)]:
