@@ -62,11 +62,12 @@ def bench_conv(T, H, W, Cin, Cout, k=(3, 3, 3), tiled=False, resid=False):
     b = torch.zeros(Cout, device=dev)
     out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
     res = rb(T, H, W, Cout) if resid else None
+    stats = tiled and os.environ.get("SVR2_KB_GNSTATS") == "1"      # also reduce the GroupNorm partial sums, like the VAE does
     fn = lambda: hip.conv3d(x, w, Cout, k, npad=k[0] - 1, pad_hw=(k[1] // 2,) * 4, bias=b, out=out, resid=res,
-                            w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS)
+                            w_layout=hip.WL_TILED_128x32 if tiled else hip.WL_ROWS, gn_stats=stats)
     t = timeit(fn)
     fl = 2 * T * H * W * Cin * Cout * k[0] * k[1] * k[2]
-    tag = ("halo/tiled" if tiled else "tap-staged") + ("+resid" if resid else "")
+    tag = ("halo/tiled" if tiled else "tap-staged") + ("+resid" if resid else "") + ("+stats" if stats else "")
     print(f"conv3d[{tag}] T={T} {H}x{W} {Cin}->{Cout} k={k}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
