@@ -21,7 +21,8 @@
 #include <stdlib.h>
 
 // Timing experiments only (-DSVR2_G4_DBG=mask builds a library with WRONG results): 1 no DMA in the K loop,
-// 2 no fragment reads in the K loop, 4 register-staged loads (issue cost only) instead of LDS-DMA.
+// 2 no fragment reads in the K loop, 4 register-staged loads (issue cost only) instead of LDS-DMA,
+// 8 every K-step loads the tile of K-step 0 again (same instruction stream, cache-hot source).
 #ifndef SVR2_G4_DBG
 #define SVR2_G4_DBG 0
 #endif
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(NT4, 2) void gemm4_kernel(const KArgs a) {
     auto issue_sub = [&](int k) {                         // sub-tile (k, part) -> sub-stage (2k + part) % 5
         char* dst = smem + ((2 * k + part) % NSUB4) * SUB4 + (isA ? 0 : 16 * 1024) + (wg & 1) * 8 * 1024;
         if (fast) {
-            const char* ub = ubase + k * (BK4 * 2);
+            const char* ub = ubase + ((SVR2_G4_DBG & 8) ? 0 : k) * (BK4 * 2);   // DBG 8: every K-step re-reads K-step 0 (cache-hot source)
 #if SVR2_G4_DBG & 4     // timing build (WRONG results): the pieces as global_load_dwordx4 into registers + ds_write_b128
             // of whatever the registers hold - the issue cost of register-staged loads without their data dependency
             // (all eight loads return into the SAME four registers, which stay reserved until the K loop ends: a load that
