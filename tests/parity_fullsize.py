@@ -67,8 +67,11 @@ row = {"input": f"[{NFR},{HIN},{WIN},3] -> {RES}p, batch_size {BSZ}, seed 42, co
 print(row, flush=True)
 refs = {}
 limit = float(os.environ.get("SVR2_PARITY_BUDGET_S", "1000"))
+only = os.environ.get("SVR2_PARITY_ONLY")          # "fp32": just that oracle flavour (it needs most of a 20-minute call alone)
 for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
-    if name == "fp32" and (time.time() - t_start) * 2.2 > limit:      # the second oracle run would not fit
+    if only and name != only:
+        continue
+    if name == "fp32" and not only and (time.time() - t_start) * 2.2 > limit:      # the second oracle run would not fit
         row["fp32"] = "skipped: time limit"
         break
     t0 = time.time()
