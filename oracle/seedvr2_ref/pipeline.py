@@ -146,7 +146,7 @@ def blur_timestep(latent_shape, scale: float, dtype=torch.bfloat16, T: float = 1
 
 def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, resolution: int, batch_size: int = 5,
              temporal_overlap: int = 0, seed: int = 42, dtype=torch.float32, uniform_batch_size: bool = False,
-             taps: dict | None = None, color_correction: str = "none", input_noise_scale: float = 0.0,
+             taps: dict | None = None, color_correction="none", input_noise_scale: float = 0.0,
              latent_noise_scale: float = 0.0, rope_mode: str = "3b") -> torch.Tensor:
     """frames [N,H,W,3] float in [0,1] -> [N,true_h,true_w,3] in [0,1] (dtype bf16 storage between phases,
     model arithmetic in `dtype`).  rope_mode "3b" | "7b" | "none" selects the DiT's rotary embedding."""
@@ -190,8 +190,15 @@ def generate(frames: torch.Tensor, vae_p, vae_cfg, dit_p, dit_cfg, text_pos, res
         written.append((write, write + sample.shape[0], xin.contiguous()))
         write += sample.shape[0]
     final = final[:write]
-    if color_correction != "none":                                    # generation_phases.py:1290-1304
-        from . import color as _color
-        for ws, we, xin in written:
-            final[ws:we] = _color.color_correct(final[ws:we].contiguous(), xin, color_correction)
-    return final.clamp(-1, 1).mul(0.5).add(0.5)                       # generation_phases.py:1337
+
+    def phase4(method):
+        out = final.clone()
+        if method != "none":                                          # generation_phases.py:1290-1304
+            from . import color as _color
+            for ws, we, xin in written:
+                out[ws:we] = _color.color_correct(out[ws:we].contiguous(), xin, method)
+        return out.clamp(-1, 1).mul(0.5).add(0.5)                     # generation_phases.py:1337
+
+    if isinstance(color_correction, (tuple, list)):   # several phase-4 flavours of ONE model pass (tests: the models run once)
+        return {m: phase4(m) for m in color_correction}
+    return phase4(color_correction)
