@@ -42,6 +42,7 @@ WORKLOADS = {
     "cfg2": ("3b", 8, 9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8-frame (padded to 9) 540p->1080p (BASELINE configs[1])"),
     "cfg1": ("3b", 1, 1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
     "cfg2o": ("3b", 26, 9, 540, 960, 1080, 4, "rehearsal: 540p->1080p clip of 26 frames, batch 9, overlap 4 (exercises blend + neighbour exchange)"),
+    "cfg0": ("3b", 26, 9, 32, 48, 64, 4, "rehearsal of the launcher / exchange / JSON contract: 32x48 -> 64x96 clip of 26 frames, batch 9, overlap 4"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
@@ -192,25 +193,143 @@ def _dit_flops(T, H, W, model="3b"):
     return 32 * 2.0 * L * (2560 * 7680 + 2560 * 2560 + 3 * 2560 * 6912)  # GEMMs only (95 % of the DiT)
 
 
-def main():
+class Runtime:
+    """What `main` needs from the machine.  The defaults are the product: one HIP device per rank, RCCL, the HIP pipeline.
+    tests/bench_cpu_child.py substitutes a CPU flavour (gloo, a per-frame stand-in for the models) to drive the
+    self-launch, the segment arithmetic, the exchange and the JSON contract without a GPU - the same role
+    `inference_cli.Runtime` plays for the CLI."""
+
+    def __init__(self):
+        self.child_cmd = [sys.executable, os.path.abspath(__file__)]
+        self.backend = os.environ.get("SVR2_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 control flow on one GPU
+
+    def device(self, local, rank):
+        ndev = torch.cuda.device_count()                          # counting devices does not initialise the GPU
+        if self.backend == "gloo":
+            local = local % max(ndev, 1)
+        elif local >= ndev:
+            raise SystemExit(f"bench: rank {rank} wants cuda:{local} but this node shows {ndev} GPU(s) "
+                             f"(SVR2_BENCH_BACKEND=gloo rehearses several ranks on one GPU)")
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def package(self, dev):
+        pkg = ge.load_package()
+        pkg.hip.device_check(dev.index)        # raises unless gfx950 + the HIP library: there is no fallback path
+        return pkg
+
+    def build(self, pkg, model, dev):
+        """(pipeline, VAE state dict, DiT state dict): random-init weights of the real architecture."""
+        vcfg = pkg.vae.VAEConfig()
+        if os.environ.get("SVR2_DECODE_SPLIT"):   # A/B of the temporal chunk sizes (results do not depend on them)
+            vcfg.decode_split = int(os.environ["SVR2_DECODE_SPLIT"])
+        if os.environ.get("SVR2_ENCODE_SPLIT"):
+            vcfg.encode_split = int(os.environ["SVR2_ENCODE_SPLIT"])
+        vsd = pkg.vae.synthetic_state_dict(vcfg, dev, seed=1)
+        vae = pkg.vae.VideoVAEHip(vcfg, vsd, dev)
+        dcfg = pkg.dit.CFG_7B if model == "7b" else pkg.dit.CFG_3B
+        dsd = pkg.dit.synthetic_state_dict(dcfg, dev, seed=2)
+        dit = pkg.dit.NaDiTHip(dcfg, dsd, dev)
+        gtxt = torch.Generator(device="cpu").manual_seed(3)
+        text_pos = (0.5 * torch.randn(58, 5120, generator=gtxt)).to(torch.bfloat16)  # shape of the shipped pos_emb.pt
+        return pkg.pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev), vsd, dsd
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def reset_peak(self):
+        torch.cuda.reset_peak_memory_stats()
+
+    def peak_gb(self):
+        return torch.cuda.max_memory_reserved() / 1e9, torch.cuda.max_memory_allocated() / 1e9
+
+    def allocated_gib(self):
+        return torch.cuda.memory_allocated() / 2**30
+
+    def event(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+
+def self_launch(n: int, argv, rt) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh ranks of this script, one per GPU,
+    BEFORE anything here has touched a GPU (this parent never does: no torch.cuda call, no package load), with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, like the reference's entry point spawns its own
+    workers [ref: inference_cli.py:1048-1112].  Rank 0 prints the one JSON line on the inherited stdout; the first
+    failing rank takes the others down and the exit code is non-zero.  torchrun-launched ranks never come here."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, failed = [], 0
+
+    def stop_children(*_):
+        for p in procs:                     # exactly the processes started below
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 15
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_term(signum, frame):
+        stop_children()
+        sys.exit(128 + signum)
+
+    try:
+        signal.signal(signal.SIGTERM, on_term)
+    except ValueError:              # not the main thread: the finally clause below still cleans up
+        pass
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), SVR2_BENCH_SELF_LAUNCHED="1",
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen(rt.child_cmd + list(argv), env=env))
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                failed = bad[0].returncode
+                break
+            time.sleep(0.2)
+    finally:
+        stop_children()
+    codes = [p.wait() for p in procs]
+    if failed or any(codes):
+        log(f"bench: rank exit codes {codes}")
+        return 1
+    return 0
+
+
+def main(argv=None, rt: Runtime = None):
+    rt = rt or Runtime()
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("SVR2_BENCH_WORKLOAD", "cfg3"), choices=list(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own clip, a step = one temporal batch per rank; strong: ONE clip split over "
+                         "the ranks like the reference's multi-GPU CLI, a step = the whole clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, argv, rt))      # nothing above this line initialises a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    backend = os.environ.get("SVR2_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 control flow on one GPU
-    if backend == "gloo":
-        local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: refusing to report a "
+                         f"number under the wrong n_gpus")
+    backend = rt.backend
+    dev = rt.device(local, rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -218,38 +337,46 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group(backend="gloo")
+    cdev = dev if backend == "nccl" else "cpu"                   # where the few control all-reduces live
 
-    pkg = ge.load_package()
+    pkg = rt.package(dev)
     hip = pkg.hip
-    hip.device_check(local)
 
     model, clip, bsz, hin, win, res, overlap, desc = WORKLOADS[args.workload]
-    if args.workload == "cfg5" and rank == world - 1:
-        clip -= overlap            # the last rank's segment has no overlap frames [ref: inference_cli.py:1091-1093]
+    strong = args.scaling == "strong"
+    seg0 = 0
+    if strong:
+        # ONE clip, split like the reference's multi-GPU mode: base + remainder frames per rank, + `overlap` for all but the
+        # last rank [ref: inference_cli.py:1082-1097]; every rank synthesises the same clip and keeps its own segment
+        if args.workload == "cfg5":
+            clip = 512
+        total = clip
+        ranges = pkg.parallel.segment_ranges(total, world, overlap, bsz, True)
+        seg0, seg1 = ranges[rank]
+        clip = seg1 - seg0
+        seg_counts = [b - a for a, b in ranges]
+    else:
+        if args.workload == "cfg5" and rank == world - 1 and world > 1:
+            clip -= overlap        # the last rank's segment has no overlap frames [ref: inference_cli.py:1091-1093]
+        seg_counts = [WORKLOADS[args.workload][1]] * world
+        if args.workload == "cfg5" and world > 1:
+            seg_counts[-1] -= overlap
+        total = sum(pkg.parallel.owned_counts(seg_counts, overlap if world > 1 else 0))
     t_build = time.time()
-    vcfg = pkg.vae.VAEConfig()
-    if os.environ.get("SVR2_DECODE_SPLIT"):   # A/B of the temporal chunk sizes (results do not depend on them)
-        vcfg.decode_split = int(os.environ["SVR2_DECODE_SPLIT"])
-    if os.environ.get("SVR2_ENCODE_SPLIT"):
-        vcfg.encode_split = int(os.environ["SVR2_ENCODE_SPLIT"])
-    vsd = pkg.vae.synthetic_state_dict(vcfg, dev, seed=1)
-    vae = pkg.vae.VideoVAEHip(vcfg, vsd, dev)
-    dcfg = pkg.dit.CFG_7B if model == "7b" else pkg.dit.CFG_3B
-    dsd = pkg.dit.synthetic_state_dict(dcfg, dev, seed=2)
-    dit = pkg.dit.NaDiTHip(dcfg, dsd, dev)
+    pipe, vsd, dsd = rt.build(pkg, model, dev)
     keep_sd = args.workload == "cfg1" and not args.no_cpu_baseline and world == 1   # the oracle runs the same weights
     if not keep_sd:
         vsd = dsd = None
-    gtxt = torch.Generator(device="cpu").manual_seed(3)
-    text_pos = (0.5 * torch.randn(58, 5120, generator=gtxt)).to(torch.bfloat16)  # shape of the shipped pos_emb.pt
-    pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, text_pos, dev)
-    torch.cuda.synchronize()
-    log(f"[rank {rank}] models built in {time.time() - t_build:.1f}s; weights {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
+    rt.sync()
+    log(f"[rank {rank}] models built in {time.time() - t_build:.1f}s; weights {rt.allocated_gib():.1f} GiB")
 
     rh, rw, th, tw, ph, pw = pkg.pipeline.target_dims(hin, win, res)
     batches, overlap = pkg.pipeline.plan_batches(clip, bsz, overlap)
     nb = len(batches)
-    lr = synth_lr_video(clip, hin, win, 1234 + rank, dev)         # the rank's LR segment, resident in HBM before timing
+    if strong:     # the same clip on every rank (one seed), this rank's segment of it resident in HBM before timing
+        lr = synth_lr_video(total, hin, win, 1234, "cpu")[seg0:seg0 + clip].to(dev)
+    else:
+        lr = synth_lr_video(clip, hin, win, 1234 + rank, dev)     # the rank's own clip, resident in HBM before timing
     streamed = args.workload == "cfg5"
     if streamed:   # held as the container's 8-bit pixels; every batch is converted on the device like video_io's reader does
         lr_u8 = (lr.float() * 255.0).round().to(torch.uint8).reshape(clip, -1).contiguous()
@@ -258,7 +385,7 @@ def main():
     idx_dev = [torch.tensor(b.index, device=dev) for b in batches]
     w_prev = pkg.pipeline.blend_weights(overlap).to(dev) if overlap else None
     final = torch.empty(clip, th, tw, 3, dtype=torch.bfloat16, device=dev)   # the clip's output, written batch by batch
-    state = {"write": 0, "frames": 0, "clips": 0}
+    state = {"write": 0, "frames": 0, "clips": 0, "exchange_s": 0.0, "exchanges": 0}
 
     ktimer = KernelTimer()
     # the roofline kernel = conv_halo_kernel (all three geometries): the conv3d calls with the tiled weight layout
@@ -266,10 +393,23 @@ def main():
     hip.conv3d = ktimer.wrap(hip.conv3d, lambda out, x, w, cout, k, *a, **kw: 2.0 * out.numel() * x.shape[3] * k[0] * k[1] * k[2])
     pkg.vae.hip = hip
 
-    def step(i):
-        """Batch i % nb of the clip through P1..P7, as SeedVR2Pipeline.generate walks it
+    def exchange(out):
+        """The boundary exchange of a finished segment (timed on its own: HIP events around it over RCCL, where the
+        current stream waits for the transfer; wall clock for the host-staged gloo rehearsal)."""
+        if backend == "gloo":          # gloo p2p needs host tensors (rehearsal only)
+            t0 = time.perf_counter()
+            res_ = pkg.parallel.exchange_and_blend(out.float().cpu(), overlap, rank, world, dist, seg_counts).to(dev)
+            state["exchange_s"] += time.perf_counter() - t0
+        else:
+            e0 = rt.event()
+            res_ = pkg.parallel.exchange_and_blend(out, overlap, rank, world, dist, seg_counts)
+            state.setdefault("exchange_events", []).append((e0, rt.event()))
+        state["exchanges"] += 1
+        return res_
+
+    def run_batch(bi):
+        """Batch bi of the rank's clip through P1..P7, as SeedVR2Pipeline.generate walks it
         [ref: src/core/generation_phases.py:342-521, 650-753, 904-1026, 1337]."""
-        bi = i % nb
         b = batches[bi]
         if bi == 0:
             state["write"] = 0
@@ -293,20 +433,26 @@ def main():
         if bi == nb - 1:                       # segment complete: [0,1] frames, then the boundary exchange
             out = hip.crop_to_unit(final[: state["write"]], th, tw, to_unit=True)
             if world > 1 and overlap:
-                if backend == "gloo":          # gloo p2p needs host tensors (rehearsal only)
-                    out = pkg.parallel.exchange_and_blend(out.float().cpu(), overlap, rank, world, dist).to(dev)
-                else:
-                    out = pkg.parallel.exchange_and_blend(out, overlap, rank, world, dist)
+                out = exchange(out)
                 state["frames"] -= state["write"] - out.shape[0]   # frames handed to the left neighbour
             state["clips"] += 1
             return out
         return None
 
+    def step(i):
+        """weak: one temporal batch of the rank's clip (cycling through its batches); strong: the rank's whole segment of
+        the shared clip, i.e. one finished clip per step over all ranks."""
+        if strong:
+            for bi in range(nb):
+                run_batch(bi)
+        else:
+            run_batch(i % nb)
+
     def barrier():
-        torch.cuda.synchronize()
+        rt.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.sync()
 
     if world > 1 and overlap:   # first use of a send/recv pair sets up its RCCL channel: not part of any step
         dummy = torch.zeros(overlap + 1, 8, 8, 3, dtype=torch.bfloat16, device=dev)
@@ -314,27 +460,39 @@ def main():
     for i in range(args.warmup):
         t0 = time.time()
         step(i)
-        torch.cuda.synchronize()
-        log(f"[rank {rank}] warmup step {i} (batch of {len(batches[i % nb].index)} frames): {time.time() - t0:.2f}s")
-    torch.cuda.reset_peak_memory_stats()
-    state.update(frames=0, clips=0)
+        rt.sync()
+        what = f"segment of {clip} frames" if strong else f"batch of {len(batches[i % nb].index)} frames"
+        log(f"[rank {rank}] warmup step {i} ({what}): {time.time() - t0:.2f}s")
+    rt.reset_peak()
+    state.update(frames=0, clips=0, exchange_s=0.0, exchanges=0)
+    state.pop("exchange_events", None)
     ktimer.enabled = True
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    rt.sync()
+    dt_own = time.perf_counter() - t0          # this rank's own time, before it waits for the slowest one
     barrier()
     dt = time.perf_counter() - t0
     ktimer.enabled = False
     frames_done = state["frames"]
+    exch_s = state["exchange_s"] + sum(a.elapsed_time(b) for a, b in state.get("exchange_events", [])) * 1e-3
+    ranks_seen, own_ms = 1, [dt_own / args.steps * 1e3]
+    exch_ms = [exch_s * 1e3 / max(args.steps, 1)]
     if world > 1:
-        tt = torch.tensor([dt, 0.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
-        ff = torch.tensor([float(frames_done)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        ranks_seen = dist.get_world_size()
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ff = torch.tensor([float(frames_done)], device=cdev, dtype=torch.float64)
         dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        per = torch.zeros(world, 2, device=cdev, dtype=torch.float64)   # every rank's own ms per step and exchange ms
+        per[rank, 0], per[rank, 1] = own_ms[0], exch_ms[0]
+        dist.all_reduce(per, op=dist.ReduceOp.SUM)
         dt, frames_done = float(tt[0].item()), int(ff.item())
-    peak_gb = torch.cuda.max_memory_reserved() / 1e9
-    log(f"[rank {rank}] peak reserved {peak_gb:.1f} GB, peak allocated {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
+        own_ms, exch_ms = per[:, 0].tolist(), per[:, 1].tolist()
+    peak_gb, peak_alloc_gb = rt.peak_gb()
+    log(f"[rank {rank}] peak reserved {peak_gb:.1f} GB, peak allocated {peak_alloc_gb:.1f} GB")
 
     if rank == 0:
         nl, kt, kf = ktimer.summary()
@@ -348,7 +506,7 @@ def main():
             per_batch[str(T)] = {"vae_encode": enc_f / 1e12, "dit_gemm": _dit_flops(T, ph, pw, model) / 1e12, "vae_decode": dec_f / 1e12}
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
         traffic, tsrc = None, None   # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes of this workload
-        for name in ("r02_hbm_traffic_cfg3.json", "r01_hbm_traffic_cfg3.json"):
+        for name in ("r03_hbm_traffic_cfg3.json", "r02_hbm_traffic_cfg3.json", "r01_hbm_traffic_cfg3.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if args.workload == "cfg3" and os.path.exists(tpath):
                 try:
@@ -359,20 +517,32 @@ def main():
                 except Exception:
                     traffic = None
         metric = "upscaled frames/sec + peak HBM GB, SeedVR2-3B 720p->4K, 1/2/4/8 MI355X"
+        if strong:
+            step_desc = ("one whole clip: every rank walks the batches of its segment of the SAME clip (reference split, "
+                         "inference_cli.py:1082-1097), then the boundary exchange")
+        else:
+            step_desc = "one temporal batch of the clip (noise generation + upload inside), cycling through the clip's batches"
         result = {
             "metric": metric,
             "value": frames_done / dt,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "peak_hbm_gb": peak_gb,
-            "config": {"workload": f"{args.workload}: {desc}", "clip_frames_per_rank": clip, "batch_size": bsz,
+            "ranks_seen": ranks_seen, "launcher": "self" if os.environ.get("SVR2_BENCH_SELF_LAUNCHED") else
+                                                  ("torchrun/env" if world > 1 else "single"),
+            "backend": backend if world > 1 else None,
+            "rank_ms_per_step": {"min": min(own_ms), "max": max(own_ms)},
+            "exchange_ms": {"per_step_max": max(exch_ms), "per_step_min": min(exch_ms),
+                            "exchanges_rank0": state["exchanges"]} if world > 1 else None,
+            "config": {"workload": f"{args.workload}: {desc}", "clip_frames_per_rank": clip, "clip_frames_total": total,
+                       "segment_frames_by_rank": seg_counts, "batch_size": bsz,
                        "temporal_overlap": overlap, "frames_per_batch": [len(b.index) for b in batches],
                        "finished_frames": frames_done, "clips_completed_rank0": state["clips"],
                        "lr": [hin, win], "out": [th, tw], "padded": [ph, pw], "parallelism": f"frame-chunk x{world}",
-                       "step": "one temporal batch of the clip (noise generation + upload inside), cycling through the clip's batches",
+                       "step": step_desc,
                        "algorithmic_tflop_per_batch_by_frames": per_batch},
             "roofline": {"bound": "mfma", "kernel": "conv_halo_wr_kernel<16,256|32,128> + conv_halo_kernel<64,16> (halo-resident causal conv3d: every 3x3 stride-1 conv of the VAE)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -389,6 +559,7 @@ def main():
                                           "sample": f"failed: {e!r}"}
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -198,7 +199,9 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
         return n
     # multi-GPU: every rank streams its own segment [ref: inference_cli.py:452-471, 1048-1209], boundaries are cross-faded
     # through the neighbour exchange, rank 0 writes
-    s, e = pkg.parallel.segment_ranges(todo, world, a.temporal_overlap, a.batch_size, True)[rank]
+    ranges = pkg.parallel.segment_ranges(todo, world, a.temporal_overlap, a.batch_size, True)
+    s, e = ranges[rank]
+    counts = [hi - lo for lo, hi in ranges]   # finished frames per rank: local arithmetic, no count exchange
     reader.seek(first + s)
     src, coll = vio.DeviceSource(reader, dev), _CollectSink()
     try:
@@ -207,8 +210,8 @@ def process_single_file(input_path: str, a, pkg, dev: str, dit_cfg, vae_cfg, tex
     finally:
         src.close()
     mine = torch.cat(coll.parts, dim=0) if coll.parts else torch.empty(0, 1, 1, 3, dtype=torch.bfloat16, device=dev)
-    owned = pkg.parallel.exchange_and_blend(mine, a.temporal_overlap, rank, world, dist)
-    full = pkg.parallel.gather_frames(owned, rank, world, 0, dist)
+    owned = pkg.parallel.exchange_and_blend(mine, a.temporal_overlap, rank, world, dist, counts)
+    full = pkg.parallel.gather_frames(owned, rank, world, 0, dist, pkg.parallel.owned_counts(counts, a.temporal_overlap))
     if rank != 0:
         return 0
     sink = sink_for(full.shape[2], full.shape[1])
@@ -224,35 +227,58 @@ def fan_out(devs: List[str], argv: List[str], rt: Runtime) -> int:
     their frames to the parent through host shared memory, the children exchange segment boundaries among themselves on
     the devices and rank 0 writes the output.  Returns 0 when every child did; the first failing child takes the others
     down (the reference's parent would wait forever on its queue)."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for i in range(len(devs)):
-        env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(len(devs)), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen(rt.child_cmd + list(argv), env=env))
-    failed = 0
-    while any(p.poll() is None for p in procs):
-        bad = [p for p in procs if p.poll() not in (None, 0)]
-        if bad:
-            failed = bad[0].returncode
-            for p in procs:                      # exactly the processes started above
-                if p.poll() is None:
-                    p.terminate()
-            deadline = time.time() + 10
-            for p in procs:
-                try:
-                    p.wait(timeout=max(0.1, deadline - time.time()))
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(rt.poll_seconds)
+    procs, failed = [], 0
+
+    def stop_children(*_):
+        for p in procs:                          # exactly the processes started below
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_term(signum, frame):
+        stop_children()
+        sys.exit(128 + signum)
+
+    old_term = None
+    try:
+        try:
+            old_term = signal.signal(signal.SIGTERM, on_term)
+        except ValueError:                       # not the main thread (tests): the finally clause still cleans up
+            old_term = None
+        port = free_port()
+        for i in range(len(devs)):
+            env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(len(devs)), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen(rt.child_cmd + list(argv), env=env))
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                failed = bad[0].returncode
+                break
+            time.sleep(rt.poll_seconds)
+    finally:
+        # also on KeyboardInterrupt / a Popen that raised for a later rank: no worker is left blocked in the rendezvous
+        stop_children()
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
     codes = [p.wait() for p in procs]
     if failed or any(codes):
         print(f"Error: multi-GPU worker exit codes {codes}", file=sys.stderr)
         return 1
     return 0
+
+
+def free_port() -> int:
+    """A rendezvous port for one run.  Picked by bind-and-close, so another process could take it before rank 0 binds it:
+    the children then fail their rendezvous and the run ends non-zero (never retried inside a process that touched a GPU)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def main(argv=None, runtime: Runtime = None) -> int:

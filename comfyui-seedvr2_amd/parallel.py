@@ -12,7 +12,7 @@ multi-GPU mode, which ships every worker's whole output through host shared memo
 
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -74,35 +74,53 @@ def _host_staged(frames: torch.Tensor, dist) -> bool:
         return False
 
 
-def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int, dist=None) -> torch.Tensor:
+def owned_counts(counts: Sequence[int], overlap: int) -> List[int]:
+    """Frames every rank owns AFTER the boundary exchange, from the finished-frame counts before it: later ranks
+    contribute chunk[overlap:] (nothing when chunk.shape[0] <= overlap) [ref: inference_cli.py:1163-1198]."""
+    if overlap <= 0:
+        return list(counts)
+    return [c if r == 0 else (c - overlap if c > overlap else 0) for r, c in enumerate(counts)]
+
+
+def _p2p(ops, dist):
+    """All of a rank's sends and receives of one exchange as ONE group: over RCCL a lone isend and a lone irecv go to
+    different per-peer communicators and can serialise against each other; a batch is one ncclGroup."""
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv([dist.P2POp(op, t, peer) for op, t, peer in ops]):
+        req.wait()
+
+
+def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int, dist=None,
+                       counts: Optional[Sequence[int]] = None) -> torch.Tensor:
     """frames: this rank's finished frames [T,H,W,C] (any float dtype, on the rank's device).
+    counts: the finished-frame count of EVERY rank before the exchange - local arithmetic on every rank (the segment
+    split is deterministic: `segment_ranges`), so no control message is needed; None = every rank holds `T` frames.
     Returns the frames this rank owns after the boundary exchange: tail blended with the right neighbour's
-    head, own head (already blended by the left neighbour) dropped.  No collective besides the
+    head, own head (already blended by the left neighbour) dropped.  The only communication is one grouped
     neighbour send/recv; ranks with too few frames follow the reference's edge cases."""
     if world <= 1 or overlap <= 0:
         return frames
     if dist is None:
         import torch.distributed as dist
     T = frames.shape[0]
+    counts = [T] * world if counts is None else [int(c) for c in counts]
+    if len(counts) != world or counts[rank] != T:
+        raise ValueError(f"rank {rank}: holds {T} frames but the segment plan says {counts}")
     staged = _host_staged(frames, dist)
     cdev = "cpu" if staged else frames.device
     # frame counts of the neighbours decide whether a boundary is blended (reference: chunk.shape[0] > overlap)
-    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
-    counts[rank] = T
-    dist.all_reduce(counts)  # tiny control message (8 bytes per rank)
-    counts = counts.tolist()
-    reqs = []
     recv = None
     send_ok = rank > 0 and T > overlap and counts[rank - 1] >= overlap
     recv_ok = rank < world - 1 and counts[rank + 1] > overlap and T >= overlap
+    ops = []
     if send_ok:
         head = frames[:overlap].contiguous()
-        reqs.append(dist.isend(head.cpu() if staged else head, rank - 1))
+        ops.append((dist.isend, head.cpu() if staged else head, rank - 1))
     if recv_ok:
         recv = torch.empty_like(frames[:overlap], device=cdev)
-        reqs.append(dist.irecv(recv, rank + 1))
-    for r in reqs:
-        r.wait()
+        ops.append((dist.irecv, recv, rank + 1))
+    _p2p(ops, dist)
     if recv is not None and staged:
         recv = recv.to(frames.device)
     out = frames
@@ -116,30 +134,28 @@ def exchange_and_blend(frames: torch.Tensor, overlap: int, rank: int, world: int
     return out
 
 
-def gather_frames(frames: torch.Tensor, rank: int, world: int, dst: int = 0, dist=None) -> Optional[torch.Tensor]:
-    """Optional second step: collect every rank's owned frames on the writer rank (point-to-point)."""
+def gather_frames(frames: torch.Tensor, rank: int, world: int, dst: int = 0, dist=None,
+                  counts: Optional[Sequence[int]] = None) -> Optional[torch.Tensor]:
+    """Optional second step: collect every rank's owned frames on the writer rank (point-to-point, one group).
+    counts: frames every rank holds NOW (`owned_counts` of the segment plan); None = `frames.shape[0]` everywhere."""
     if world <= 1:
         return frames
     if dist is None:
         import torch.distributed as dist
+    counts = [frames.shape[0]] * world if counts is None else [int(c) for c in counts]
+    if len(counts) != world or counts[rank] != frames.shape[0]:
+        raise ValueError(f"rank {rank}: holds {frames.shape[0]} frames but the segment plan says {counts}")
     staged = _host_staged(frames, dist)
     cdev = "cpu" if staged else frames.device
-    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
-    counts[rank] = frames.shape[0]
-    dist.all_reduce(counts)
-    counts = counts.tolist()
     if rank != dst:
         if frames.shape[0] > 0:
-            dist.send(frames.contiguous().cpu() if staged else frames.contiguous(), dst)
+            _p2p([(dist.isend, frames.contiguous().cpu() if staged else frames.contiguous(), dst)], dist)
         return None
-    parts = []
-    for r in range(world):
-        if r == dst:
-            parts.append(frames)
-        elif counts[r] > 0:
-            buf = torch.empty((counts[r],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=cdev)
-            dist.recv(buf, r)
-            parts.append(buf.to(frames.device) if staged else buf)
+    bufs = {r: torch.empty((counts[r],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=cdev)
+            for r in range(world) if r != dst and counts[r] > 0}
+    _p2p([(dist.irecv, b, r) for r, b in bufs.items()], dist)
+    parts = [frames if r == dst else (bufs[r].to(frames.device) if staged else bufs[r])
+             for r in range(world) if r == dst or r in bufs]
     return torch.cat(parts, dim=0)
 
 
@@ -150,9 +166,11 @@ def upscale_distributed(generate, frames: torch.Tensor, overlap: int, rank: int,
     boundaries are cross-faded through the neighbour exchange, and (gather_to is not None) the finished frames are
     collected on rank `gather_to`.  Returns the gathered clip on that rank (None elsewhere), or this rank's owned frames
     when gather_to is None."""
-    s, e = segment_ranges(frames.shape[0], world, overlap, batch_size, streaming)[rank]
+    ranges = segment_ranges(frames.shape[0], world, overlap, batch_size, streaming)
+    s, e = ranges[rank]
+    counts = [b - a for a, b in ranges]     # an upscaled segment has as many frames as its input: no count exchange
     mine = generate(frames[s:e])
-    owned = exchange_and_blend(mine, overlap, rank, world, dist)
+    owned = exchange_and_blend(mine, overlap, rank, world, dist, counts)
     if gather_to is None:
         return owned
-    return gather_frames(owned, rank, world, gather_to, dist)
+    return gather_frames(owned, rank, world, gather_to, dist, owned_counts(counts, overlap))
