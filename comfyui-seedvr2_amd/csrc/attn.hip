@@ -220,15 +220,12 @@ __global__ __launch_bounds__(NTH, (HD <= 128 ? (KT <= 32 ? 3 : 2) : 1)) void fla
     }
 }
 
-// ---- second-generation window-attention kernel (HD = 128): same algorithm, same tile geometry and the same
-// summation order as flash_attn_kernel (bit-identical results for equal KT), but the LDS fragment reads are issued one
-// GROUP ahead of the MFMAs that consume them.  hipcc's own schedule of the kernel above is read -> s_waitcnt lgkmcnt(0)
-// -> MFMA for every single MFMA (one fragment register set, re-used), which exposes an LDS round trip (~100 cycles) in
-// front of each 32-cycle MFMA; here a group = the 8 K fragments of a 32-key half (QK^T) or the 8 transposed V reads of a
-// 16-key step (PV), two register sets, group g+1 is requested before the MFMAs of group g, and sched_barrier keeps that
-// order, so the compiler's counted lgkmcnt lets the MFMAs issue back to back.  The first V group is requested before
-// the softmax arithmetic, which hides it completely.
-template <int KT, bool AHEAD>
+// ---- second-generation window-attention kernel (HD = 128), the default: same algorithm, same tile geometry and the same
+// summation order as flash_attn_kernel (bit-identical results for equal KT) with lane-constant DMA piece offsets (one
+// 64-bit add per piece; only a sequence's last partial tile clamps rows).  The variant that requested the LDS fragment
+// groups one group ahead in a second register set was measured slower (721-737 vs 762-780 TFLOP/s at 4K: with both waves
+// of a SIMD in MFMA bursts the bursts collide; profiles/r02_attn/) and is gone.
+template <int KT>
 __global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(const AttnArgs a) {
     constexpr int HD = 128, RB = HD * 2, CPR = RB / 16, KPI = 1024 / RB;
     constexpr int TILE_BYTES = KT * RB;
@@ -311,11 +308,6 @@ __global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(co
     for (int j = 0; j < 4; ++j)
         voff[j] = (4 * hh + tq) * RB + (((((j ^ tq) & 3) << 2) | (2 * tg) | (tp >> 1)) << 4) + (tp & 1) * 8;
 
-    auto load_k = [&](const char* sK, int k2, bf16x8* kf) {
-        const char* kp = sK + k2 * 32 * RB;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kp + koff[ks]);
-    };
     auto load_v = [&](const char* sV, int g, bf16x8* vf) {      // g = k2*2 + s: the 16-key step
         const char* vrow = sV + g * 16 * RB;
 #pragma unroll
@@ -336,42 +328,20 @@ __global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(co
         const char* sK = smem + (t & 1) * TILE_BYTES;
         const char* sV = smem + (2 + (t & 1)) * TILE_BYTES;
 
-        // ---- S^T = K . Q^T, fragment groups one ahead
+        // ---- S^T = K . Q^T
         f32x16 sacc[NK2];
-        bf16x8 vfa[NDT], vfb[NDT];
-        if constexpr (AHEAD) {
-            bf16x8 kfa[NKS], kfb[NKS];
-            load_k(sK, 0, kfa);
+        bf16x8 vfa[NDT];
 #pragma unroll
-            for (int k2 = 0; k2 < NK2; ++k2) {
-                bf16x8* cur = (k2 & 1) ? kfb : kfa;
-                bf16x8* nxt = (k2 & 1) ? kfa : kfb;
-                if (k2 + 1 < NK2) load_k(sK, k2 + 1, nxt);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int k2 = 0; k2 < NK2; ++k2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
+            const char* kp = sK + k2 * 32 * RB;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ks], qf[ks], sacc[k2], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the first V group travels while the softmax arithmetic runs
-            load_v(sV, 0, vfa);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-            for (int k2 = 0; k2 < NK2; ++k2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[k2][r] = 0.f;
-                const char* kp = sK + k2 * 32 * RB;
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(kp + koff[ks]);
-                    sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
-                }
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kp + koff[ks]);
+                sacc[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
             }
         }
-
         if (t == nt - 1 && (len % KT) != 0) {
             const int kbase = t * KT + 4 * hh;
 #pragma unroll
@@ -409,24 +379,13 @@ __global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(co
             }
         l_run += psum;
 
-        // ---- O^T += V^T . P^T (AHEAD: V groups one ahead)
+        // ---- O^T += V^T . P^T
 #pragma unroll
         for (int g = 0; g < 2 * NK2; ++g) {
-            if constexpr (AHEAD) {
-                bf16x8* cur = (g & 1) ? vfb : vfa;
-                bf16x8* nxt = (g & 1) ? vfa : vfb;
-                if (g + 1 < 2 * NK2) load_v(sV, g + 1, nxt);
-                __builtin_amdgcn_sched_barrier(0);
+            load_v(sV, g, vfa);
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[dt], pf[g >> 1][g & 1], oacc[dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                load_v(sV, g, vfa);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[dt], pf[g >> 1][g & 1], oacc[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < NDT; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[dt], pf[g >> 1][g & 1], oacc[dt], 0, 0, 0);
         }
     }
 
@@ -448,11 +407,11 @@ __global__ __launch_bounds__(NTH, (KT <= 32 ? 3 : 2)) void flash_attn2_kernel(co
     }
 }
 
-template <int KT, bool AHEAD>
+template <int KT>
 int launch_attn2(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int LDS = 4 * KT * 128 * 2;
-    SVR2_SET_MAX_LDS((flash_attn2_kernel<KT, AHEAD>), LDS, "flash_attn2");
-    hipLaunchKernelGGL((flash_attn2_kernel<KT, AHEAD>), grid, dim3(NTH), LDS, s, a);
+    SVR2_SET_MAX_LDS((flash_attn2_kernel<KT>), LDS, "flash_attn2");
+    hipLaunchKernelGGL((flash_attn2_kernel<KT>), grid, dim3(NTH), LDS, s, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }
@@ -482,19 +441,15 @@ static int window_attn_impl(const void* q, const void* k, const void* v, void* o
     a.ld = (long long)H * 128; a.ldo = a.ld; a.fixed_len = 0;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.ntiles = a.total = a.per_xcd = 0;
-    // SVR2_ATTN_V (A/B, profiles/r02_attn_*): 1 = 2-D grid in dispatch order (the round-1 kernel), 2 = XCD-aware tile
-    // order, 3 = that with 32-key tiles and three workgroups per CU, 4 = 64-key tiles with the fragment groups requested
-    // ahead, 5 (default) = 32-key tiles, three workgroups per CU, one-add DMA addressing, 6 = 64-key tiles with that
-    const int ver = svr2::opt(svr2::OPT_ATTN_V, 5);
-    if (ver == 1) return launch_attn<128, 64>(a, dim3(ntiles, H, 1), (hipStream_t)stream);
+    // Both kernels: XCD-aware 1-D grid, 32-key tiles, three workgroups per CU.  Default = flash_attn2_kernel (one-add DMA
+    // addressing; the round-2 A/B of six variants is in profiles/r02_attn/, the slower ones are gone); SVR2_ATTN_V=1 =
+    // the plain flash_attn_kernel of the same tile geometry and summation order: results must be BIT-IDENTICAL
+    // (tests/test_gpu_kernels.py), which is what the switch is for.
     const long long total = (long long)ntiles * H;
     SVR2_CHECK(total < (1ll << 30), SVR2_E_SHAPE, "svr2_window_attn: too many tiles");
     a.ntiles = ntiles; a.total = (int)total; a.per_xcd = (int)((total + 7) / 8);
-    if (ver == 3) return launch_attn<128, 32>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
-    if (ver == 4) return launch_attn2<64, true>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);   // fragment groups ahead
-    if (ver == 5) return launch_attn2<32, false>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);  // cheap addressing, 3 WG/CU
-    if (ver == 6) return launch_attn2<64, false>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
-    return launch_attn<128, 64>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
+    if (svr2::opt(svr2::OPT_ATTN_V, 5) == 1) return launch_attn<128, 32>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
+    return launch_attn2<32>(a, dim3(a.per_xcd * 8, 1, 1), (hipStream_t)stream);
 }
 
 extern "C" int svr2_window_attn(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens,

@@ -66,16 +66,19 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // Every switch is resolved ONCE: from svr2_set_option if it was called, else from the environment variable of the same
 // name at first use, else the built-in default.  No getenv on the launch path.
 namespace svr2 {
-enum Opt { OPT_HALO_WR, OPT_GEMM_V, OPT_GEMM4, OPT_GEMM_BM, OPT_GEMM2_NARROW, OPT_CONV_LINEAR_TILES, OPT_ATTN_V, OPT_GEMM_DEEP, OPT_CONV_TFAST, OPT_CONV_SPLIT, OPT_COUNT };
+enum Opt { OPT_HALO_WR, OPT_GEMM_V, OPT_GEMM4, OPT_GEMM_BM, OPT_GEMM2_NARROW, OPT_CONV_LINEAR_TILES, OPT_ATTN_V, OPT_CONV_TFAST, OPT_CONV_SPLIT, OPT_COUNT };
 int opt(Opt o, int dflt);
-// hipFuncSetAttribute is a per-device setting: true exactly once per (call site, device)
-bool first_use_on_this_device(unsigned long long* mask);
+// hipFuncSetAttribute is a per-device setting, done once per (call site, device): attr_pending returns the device's bit
+// while the attribute is not set yet (0 afterwards); attr_done publishes it once the call has succeeded
+unsigned long long attr_pending(const unsigned long long* mask);
+void attr_done(unsigned long long* mask, unsigned long long bit);
 }  // namespace svr2
 #define SVR2_SET_MAX_LDS(fn, bytes, what)                                                              \
     do {                                                                                                 \
         static unsigned long long mask_ = 0;                                                             \
-        if (svr2::first_use_on_this_device(&mask_)) {                                                    \
+        if (const unsigned long long bit_ = svr2::attr_pending(&mask_)) {                                \
             hipError_t e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
             SVR2_CHECK(e_ == hipSuccess, SVR2_E_LAUNCH, "%s: cannot reserve %d bytes of LDS", what, (int)(bytes));         \
+            svr2::attr_done(&mask_, bit_);                                                               \
         }                                                                                                \
     } while (0)

@@ -32,10 +32,8 @@
 #include "gemm_args.h"
 #include <stdlib.h>
 
-// Timing experiments only (-DSVR2_HALO_DBG=mask builds a library with WRONG results): 1 = conv_halo_wr without epilogue.
-#ifndef SVR2_HALO_DBG
-#define SVR2_HALO_DBG 0
-#endif
+// The timing variant without epilogue (WRONG results, measurement only) lives in tools/timing_variants/conv_halo_dbg.patch
+// (tools/build_timing_variant.py builds it into a library of its own that the product never loads).
 
 namespace svr2 {
 namespace {
@@ -446,17 +444,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
             for (int j = 0; j < JN; ++j) img[(i * JN + j) * G::NT] = acc[i][j];
         return;
     }
-#if SVR2_HALO_DBG & 1       // timing build (WRONG results): no epilogue at all, a never-taken store keeps the accumulators alive
-    {
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < JN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (keep == 123.456f) a.C[0] = f2bf(keep);
-        return;
-    }
-#endif
     asm volatile("s_barrier" ::: "memory");
     halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
 }

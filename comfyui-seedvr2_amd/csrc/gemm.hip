@@ -330,13 +330,8 @@ int launch(const KArgs& a, hipStream_t s) {
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
     if (big) return launch_bm<AMODE, EPI, 256, 3>(a, s);
-    // tile-starved dense problems (at most one 128 x 128 workgroup per CU): SVR2_GEMM_DEEP=1 selects the 4-deep ring.
-    // Measured (tools/kernel_bench.py gemmsmallm, M = 1024): 38 us either way for N = K = 2560 - these shapes are
-    // bound by the rate at which a CU accepts 1-KiB LDS-DMA pieces (32 per 128 x 128 x 64 step, ~45 cycles each), not
-    // by the DMA latency the deeper ring hides; off by default.
-    const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (AMODE == A_DENSE && tiles1 <= 288 && a.K >= 512 && svr2::opt(svr2::OPT_GEMM_DEEP, 0) != 0)
-        return launch_bm<AMODE, EPI, 128, 4>(a, s);
+    // (a 4-deep ring for tile-starved dense problems was measured at no gain - those shapes are bound by the rate at
+    // which a CU accepts 1-KiB LDS-DMA pieces, not by the DMA latency a deeper ring hides - and is gone: DESIGN 3.2)
     return launch_bm<AMODE, EPI, 128, 2>(a, s);
 }
 
@@ -346,28 +341,33 @@ int launch(const KArgs& a, hipStream_t s) {
 namespace svr2 {
 static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
                                                  "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V",
-                                                 "SVR2_GEMM_DEEP", "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT"};
+                                                 "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT"};
 static const int kUnset = INT32_MIN;
-static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
 static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
 
 int opt(Opt o, int dflt) {
     int v = g_opt[o].load(std::memory_order_relaxed);
     if (v == kUnset) {                         // first use: the environment decides, once
         const char* e = getenv(kOptNames[o]);
-        v = e ? atoi(e) : kDefault;
-        g_opt[o].store(v, std::memory_order_relaxed);
+        int want = e ? atoi(e) : kDefault;
+        // publish only over "unset": a concurrent svr2_set_option wins and its value is what we return
+        v = g_opt[o].compare_exchange_strong(v, want, std::memory_order_relaxed) ? want : g_opt[o].load(std::memory_order_relaxed);
     }
     return v == kDefault ? dflt : v;
 }
 
-bool first_use_on_this_device(unsigned long long* mask) {
+// 0: the attribute is already set on the current device; otherwise the device's bit, which the caller publishes with
+// attr_done() AFTER hipFuncSetAttribute succeeded - a second host thread that races here sets the attribute again
+// (harmless) instead of launching with > 64 KiB of dynamic LDS before it is allowed.
+unsigned long long attr_pending(const unsigned long long* mask) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: set the attribute again
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return ~0ull;   // unknown: set the attribute every time
     const unsigned long long bit = 1ull << dev;
-    if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return false;
-    __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
-    return true;
+    return (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & bit) ? 0ull : bit;
+}
+void attr_done(unsigned long long* mask, unsigned long long bit) {
+    if (bit != ~0ull) __atomic_fetch_or(mask, bit, __ATOMIC_RELEASE);
 }
 }  // namespace svr2
 

@@ -1,6 +1,6 @@
 // Second-generation bf16 MFMA GEMM / implicit-conv3d kernel for the large problems of the path.
 //
-// Why it exists (measured on MI355X, tools/kernel_bench.py + SVR2_GEMM_DBG experiments, round 1): the 128x128x64
+// Why it exists (measured on MI355X, tools/kernel_bench.py and timing builds, round 1): the 128x128x64
 // kernel of gemm.hip runs at ~1.0-1.1 PFLOP/s; with its global->LDS DMA disabled the same loop reaches
 // 1.5-1.7 PFLOP/s, and removing only the W or only the A loads recovers 15 % / 25 %: the LDS-DMA issue rate
 // per MFMA is the limiter.  This kernel halves-to-quarters that rate:

@@ -20,17 +20,13 @@
 #include "gemm_args.h"
 #include <stdlib.h>
 
-// Timing experiments only (-DSVR2_G4_DBG=mask builds a library with WRONG results): 1 no DMA in the K loop,
-// 2 no fragment reads in the K loop, 4 register-staged loads (issue cost only) instead of LDS-DMA,
-// 8 every K-step loads the tile of K-step 0 again (same instruction stream, cache-hot source).
-#ifndef SVR2_G4_DBG
-#define SVR2_G4_DBG 0
-#endif
+// The timing variants of this kernel (no DMA / no fragment reads / register-staged loads / cache-hot source: WRONG
+// results, measurement only) are not in this file: tools/timing_variants/gemm4_dbg.patch, built by
+// tools/build_timing_variant.py into a library of its own that the product never loads.
 
 namespace svr2 {
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int BM4 = 256, BN4 = 256, BK4 = 64, NT4 = 512;
 constexpr int SUB4 = 32 * 1024;                           // one sub-stage: 128 A rows + 128 W rows of 128 bytes
@@ -79,25 +75,10 @@ __global__ __launch_bounds__(NT4, 2) void gemm4_kernel(const KArgs a) {
             arow[i] = m < a.M ? a.a_rows[m] : -1;
         }
     }
-#if SVR2_G4_DBG & 4
-    u32x4 dbg_stage = {0u, 0u, 0u, 0u};
-#endif
     auto issue_sub = [&](int k) {                         // sub-tile (k, part) -> sub-stage (2k + part) % 5
         char* dst = smem + ((2 * k + part) % NSUB4) * SUB4 + (isA ? 0 : 16 * 1024) + (wg & 1) * 8 * 1024;
         if (fast) {
-            const char* ub = ubase + ((SVR2_G4_DBG & 8) ? 0 : k) * (BK4 * 2);   // DBG 8: every K-step re-reads K-step 0 (cache-hot source)
-#if SVR2_G4_DBG & 4     // timing build (WRONG results): the pieces as global_load_dwordx4 into registers + ds_write_b128
-            // of whatever the registers hold - the issue cost of register-staged loads without their data dependency
-            // (all eight loads return into the SAME four registers, which stay reserved until the K loop ends: a load that
-            // lands late can clobber nothing else)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const char* src = ub + i * ustep + ((i & 1) ? voff1 : voff0);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_stage) : "v"(src) : "memory");
-                asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(dst + i * 1024) + lane * 16), "v"(dbg_stage) : "memory");
-            }
-            return;
-#endif
+            const char* ub = ubase + k * (BK4 * 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) glds16(ub + i * ustep + ((i & 1) ? voff1 : voff0), dst + i * 1024);
             return;
@@ -171,24 +152,21 @@ __global__ __launch_bounds__(NT4, 2) void gemm4_kernel(const KArgs a) {
         for (int k = 0; k < nk; ++k) {
             compute();                                    // phase 2k+1
             boundary(true);
-            if (k + 1 < nk && !(SVR2_G4_DBG & 2)) load_frags(k + 1);
-            if (k + 2 < nk && !(SVR2_G4_DBG & 1)) issue_sub(k + 2);   // phase 2k+2: Y_{k+2} into the sub-stage X_k just left
+            if (k + 1 < nk) load_frags(k + 1);
+            if (k + 2 < nk) issue_sub(k + 2);   // phase 2k+2: Y_{k+2} into the sub-stage X_k just left
             boundary(false);
         }
     } else {
         boundary(false);                                  // phase 0: nothing to do yet
         for (int k = 0; k < nk; ++k) {
-            if (!(SVR2_G4_DBG & 2) || k == 0) load_frags(k);
-            if (k + 2 < nk && !(SVR2_G4_DBG & 1)) issue_sub(k + 2);   // phase 2k+1: X_{k+2} into the sub-stage Y_{k-1} left
+            load_frags(k);
+            if (k + 2 < nk) issue_sub(k + 2);   // phase 2k+1: X_{k+2} into the sub-stage Y_{k-1} left
             boundary(false);
             compute();                                    // phase 2k+2
             boundary(true);
         }
     }
 
-#if SVR2_G4_DBG & 4
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(dbg_stage) : "memory");
-#endif
     // ---- epilogue: (acc + bias) -> bf16 tile in LDS -> fused epilogues on 8 consecutive columns
     {
         // lane holds, for row m = wm*128 + i*16 + frow, columns n = wn*64 + j*16 + 4*fq + r (r = 0..3)

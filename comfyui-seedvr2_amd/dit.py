@@ -88,6 +88,10 @@ class NaDiTHip:
     def _init_on_device(self, cfg: DiTConfig, params: Dict[str, torch.Tensor], timestep: float):
         self.cfg = cfg
         self._plans = {}
+        # A/B switches, resolved ONCE here (tests set the attributes; nothing on the per-block / per-call path reads the
+        # environment): graph_mode / txt_lane_mode "auto" | "0" | "1"
+        self.graph_mode = os.environ.get("SVR2_DIT_GRAPH", "auto")
+        self.txt_lane_mode = os.environ.get("SVR2_DIT_TXT_LANE", "auto")
         d = cfg.vid_dim
         dev = self.device
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -185,8 +189,8 @@ class NaDiTHip:
             assert (np.sort(out_rows) == np.arange(p.total)).all()
             self._plans[key] = {
                 "S": p.total, "L": L, "nwin": p.nwin, "src_row": up(p.src_row), "pos": up(p.pos), "cu": up(p.cu_seqlens),
-                "tile_seq": up(p.tile_seq), "tile_q0": up(p.tile_q0), "inv_rows": up(p.inv_rows),
-                "txt_row0": up(p.txt_row0), "out_rows": up(out_rows), "txt_out0": up(txt_out0),
+                "tile_seq": up(p.tile_seq), "tile_q0": up(p.tile_q0),
+                "out_rows": up(out_rows), "txt_out0": up(txt_out0),
             }
         return self._plans[key]
 
@@ -244,21 +248,16 @@ class NaDiTHip:
         qkvw = hip.qkv_prep(qkv_v, qkv_t, pl["src_row"], pl["pos"], Lv["qn"], Lv["kn"], Lt_["qn"], Lt_["kn"],
                             rc, rs, H, cfg.rope_mode, cfg.norm_eps)
         del qkv_v, qkv_t, xa, ya
-        if os.environ.get("SVR2_DIT_SCATTER", "1") != "0":
-            o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D),
-                                out_rows=pl["out_rows"])
-            del qkvw
-            o2 = o.view(pl["S"], H * D)
-            ot = hip.txt_mean(o2, pl["txt_out0"], ntxt)
-            x1 = hip.gemm(o2[: pl["L"]], Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"],
-                          resid=x)
-        else:   # A/B: window-ordered attention output, row gather fused into the projection's A loads
-            o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D))
-            del qkvw
-            o2 = o.view(pl["S"], H * D)
-            ot = hip.txt_mean(o2, pl["txt_row0"], ntxt)
-            x1 = hip.gemm(o2, Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"], resid=x,
-                          a_rows=pl["inv_rows"], m=x.shape[0])
+        # the attention kernel scatters its rows back to natural token order (video rows first, the windows' text rows
+        # behind them), so the projection is a dense GEMM; the alternative - window-ordered output, gather fused into the
+        # projection's A loads - cost 20 ms more per 4K step and is gone
+        o = hip.window_attn(qkvw[0], qkvw[1], qkvw[2], pl["cu"], pl["tile_seq"], pl["tile_q0"], 1.0 / math.sqrt(D),
+                            out_rows=pl["out_rows"])
+        del qkvw
+        o2 = o.view(pl["S"], H * D)
+        ot = hip.txt_mean(o2, pl["txt_out0"], ntxt)
+        x1 = hip.gemm(o2[: pl["L"]], Lv["w_out"], d, epilogue=hip.EPI_GATE_RES, bias=Lv["b_out"], gate=Lv["attn_gate"],
+                      resid=x)
         if side is not None:
             keep.append(ot)
             side.wait_stream(main)
@@ -298,7 +297,7 @@ class NaDiTHip:
         common/diffusion/schedules/base.py:108-110].  noise, latent: bf16 [T,H,W,16]; txt bf16 [Lt, txt_in_dim].
         Small grids replay a captured hipGraph of the whole forward pass (SVR2_DIT_GRAPH=0 disables, =1 forces):
         the pass is a fixed sequence of launches for a given grid, with no host synchronisation inside."""
-        mode = os.environ.get("SVR2_DIT_GRAPH", "auto")
+        mode = self.graph_mode
         tokens = noise.shape[0] * noise.shape[1] * noise.shape[2] // 4
         if taps is None and mode != "0" and (mode == "1" or tokens <= self.GRAPH_MAX_TOKENS):
             return self._one_step_graph(noise, latent, txt)
@@ -349,7 +348,7 @@ class NaDiTHip:
         if taps is not None:
             taps["x0"] = x; taps["y0"] = y
         # small grids: the text rows run on a lane of their own (SVR2_DIT_TXT_LANE=0 disables, =1 forces)
-        lane_mode = os.environ.get("SVR2_DIT_TXT_LANE", "auto")
+        lane_mode = self.txt_lane_mode
         txt_lane = None
         if lane_mode != "0" and (lane_mode == "1" or grid[0] * grid[1] * grid[2] <= self.GRAPH_MAX_TOKENS):
             main = torch.cuda.current_stream(self.device)

@@ -69,7 +69,7 @@ class QkvPrepDesc(C.Structure):
 _lib = None
 _zero_pages = {}
 _INT64_RET = ("svr2_groupnorm_ws_floats", "svr2_adain_ws_bytes", "svr2_hist_match_ws_bytes", "svr2_hue_sat_match_ws_bytes",
-              "svr2_jpeg_ws_bytes")
+              "svr2_jpeg_ws_bytes", "svr2_conv3d_split_ws_bytes")
 
 # every symbol include/seedvr2_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -97,6 +97,9 @@ def lib() -> C.CDLL:
             raise HipError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
                 "The SeedVR2 MI355X path has no CPU fallback.")
+        if os.environ.get("SVR2_LIB"):    # A/B builds (and tools/build_timing_variant.py): never silently
+            import sys
+            print(f"[seedvr2_amd] loading the HIP library from SVR2_LIB={LIB_PATH}", file=sys.stderr, flush=True)
         _lib = C.CDLL(LIB_PATH)
         _lib.svr2_last_error.restype = C.c_char_p
         for name in EXPORTS:
@@ -129,6 +132,10 @@ def set_option(name: str, value: Optional[int]) -> None:
     """A/B switch of the library (svr2_set_option): value None returns it to the built-in default."""
     _check(lib().svr2_set_option(name.encode(), C.c_int(0 if value is None else int(value)), C.c_int(value is None)),
            "svr2_set_option")
+    _SPLIT_WS.clear()       # SVR2_CONV_SPLIT decides which convs are split
+
+
+_SPLIT_WS: dict = {}        # conv geometry -> scratch bytes of the split-K path (asked from the library once per geometry)
 
 
 def on_device(fn):
@@ -346,8 +353,10 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
     d, _ = _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, out, w_layout,
                       part.buf if part is not None else None)
     if w_layout == WL_TILED_128x32:      # scratch of the split-K path (small grids only; 0 bytes otherwise)
-        lib().svr2_conv3d_split_ws_bytes.restype = C.c_int64
-        nws = int(lib().svr2_conv3d_split_ws_bytes(C.byref(d)))
+        key = (tuple(x.shape), cout, tuple(k), tuple(s), npad, tuple(pad_hw) if pad_hw is not None else None)
+        nws = _SPLIT_WS.get(key)
+        if nws is None:
+            nws = _SPLIT_WS[key] = int(lib().svr2_conv3d_split_ws_bytes(C.byref(d)))
         if nws > 0:
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
             d.split_ws, d.split_ws_bytes = _p(ws), nws

@@ -197,3 +197,32 @@ def test_conv_weight_tiled_layout(pkg):
         n, c = nb * 128 + r, cs * 32 + 8 * (s ^ f[(r >> 2) & 3]) + e
         want = w[n, c, a, ky, kx].item() if n < cout else 0.0
         assert t[nb, a, cs, kx, ky, r, s, e].item() == want
+
+
+def test_shipped_library_has_no_packed_f32_instructions(pkg):
+    """The build flags that keep hipcc from emitting v_pk_(fma|mul|add)_f32 are a workaround for wrong results under kernel
+    concurrency (profiles/r02_concurrency): a toolchain or flag change that brings the packed forms back must
+    fail here, not in a timing-dependent GPU test.  Disassembles every gfx950 code object of the library that ships."""
+    import __graft_entry__ as ge
+    bad = ge.packed_f32_instructions(pkg.hip.LIB_PATH)
+    assert bad == {}, bad
+
+
+def test_packed_f32_canary_is_sensitive_and_the_flags_suppress_it():
+    """The canary kernel is packed by hipcc's defaults (so the scan above can see the instruction it looks for) and is not
+    under the product's flags; the device pass knows the feature (flag_canary raises otherwise)."""
+    import __graft_entry__ as ge
+    plain = [f for f in ge.DEVICE_FLAGS if f not in ("-fno-slp-vectorize", "-Xclang", "-target-feature", "-packed-fp32-ops")]
+    assert ge.flag_canary(plain) > 0
+    assert ge.flag_canary() == 0
+
+
+def test_no_timing_variant_code_in_product_sources():
+    """Libraries with wrong results (timing experiments) are patches under tools/timing_variants/, applied to a copy."""
+    import glob
+    import __graft_entry__ as ge
+    for f in glob.glob(os.path.join(ge.PKG_DIR, "csrc", "*")):
+        text = open(f).read()
+        assert "_DBG" not in text.replace("_dbg.patch", ""), f
+    for p in glob.glob(os.path.join(ge.ROOT, "tools", "timing_variants", "*.patch")):
+        assert "_DBG" in open(p).read()

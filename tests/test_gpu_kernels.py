@@ -45,23 +45,6 @@ def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, lib_option):
     assert_close(out, a @ w.T + b, f"gemm4 {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 2560, 2560), (1000, 2560, 6912), (58, 2560, 512), (1024, 384, 576), (300, 3072, 12288)])
-def test_gemm_deep_ring_tile_starved(pkg, gpu, M, N, K, lib_option):
-    """gemm.hip, 128-row tile with the 4-deep LDS ring (tile-starved dense problems, e.g. the M = 1024 projections of a
-    512 x 512 image): same summation order as the 2-deep ring -> bit-identical to it, and within tolerance of fp32."""
-    hip = pkg.hip
-    a, w = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=1 / math.sqrt(K))
-    bias, gate, res = rnd(N, seed=13), rnd(N, seed=14), rnd(M, N, seed=15)
-    wd = hip.pad_weight(w.to(gpu))
-    args = dict(epilogue=hip.EPI_GATE_RES, bias=bias.to(gpu), gate=gate.to(gpu), resid=dev_bf16(res, gpu))
-    lib_option("SVR2_GEMM_DEEP", 1)
-    deep = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
-    lib_option("SVR2_GEMM_DEEP", 0)
-    shallow = hip.gemm(dev_bf16(a, gpu), wd, N, **args)
-    assert torch.equal(deep, shallow)
-    assert_close(deep, res + gate * (a @ w.T + bias), f"gemm deep ring {M}x{N}x{K}")
-
-
 def test_gemm4_pingpong_epilogues(pkg, gpu, lib_option):
     lib_option("SVR2_GEMM_V", 3)
     hip = pkg.hip
@@ -312,6 +295,27 @@ def test_window_attn(pkg, gpu, lens, H):
     assert_close(out, attn_ref(q, k, v, lens), f"window_attn {lens}", rtol=2e-2, atol_rel=2e-2)
 
 
+def test_window_attn_default_kernel_bit_identical_to_plain_kernel(pkg, gpu, lib_option):
+    """flash_attn2_kernel (default) and the plain flash_attn_kernel of the same tile geometry (SVR2_ATTN_V=1) share the
+    summation order: equal bits on ragged sequences incl. the rescale spike - the only reason the switch still exists."""
+    hip = pkg.hip
+    lens, H = [463, 868, 135, 64, 129, 1, 810 + 58], 3
+    S = sum(lens)
+    q, k, v = rnd(S, H, 128, seed=53), rnd(S, H, 128, seed=54), rnd(S, H, 128, seed=55)
+    k[300] = q[10] * 3.0
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    tseq, tq0 = [], []
+    for i, n in enumerate(lens):
+        for q0 in range(0, n, 128):
+            tseq.append(i); tq0.append(q0)
+    up = lambda a: torch.tensor(a, dtype=torch.int32, device=gpu)
+    args = (dev_bf16(q, gpu), dev_bf16(k, gpu), dev_bf16(v, gpu), up(cu), up(tseq), up(tq0), 1 / math.sqrt(128))
+    out_default = hip.window_attn(*args)
+    lib_option("SVR2_ATTN_V", 1)
+    out_plain = hip.window_attn(*args)
+    assert torch.equal(out_default, out_plain)
+
+
 def test_qkv_prep_and_txt_mean(pkg, gpu):
     """Window gather + per-head RMSNorm + 3B mm-rope vs the oracle's pieces."""
     from seedvr2_ref import dit as odit, rope as orope, windows as owin
@@ -412,7 +416,7 @@ def test_dit_graph_replay_equals_eager(pkg, gpu, monkeypatch):
     txt = torch.randn(58, 64, generator=g).to(torch.bfloat16).to(gpu)
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SVR2_DIT_GRAPH", mode)
+        model.graph_mode = mode
         res = []
         for seed in (1, 2, 3):
             gg = torch.Generator().manual_seed(seed)
@@ -448,8 +452,7 @@ def test_dit_txt_lane_equals_single_stream(pkg, gpu, monkeypatch, flavour):
     outs = {}
     for lane in ("0", "1"):
         for graph in ("0", "1"):
-            monkeypatch.setenv("SVR2_DIT_TXT_LANE", lane)
-            monkeypatch.setenv("SVR2_DIT_GRAPH", graph)
+            model.txt_lane_mode, model.graph_mode = lane, graph
             if hasattr(model, "_graphs"):
                 model._graphs.clear()
             res = []

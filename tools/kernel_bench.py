@@ -159,17 +159,13 @@ if __name__ == "__main__":
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
     if "gemmsmallm" in which:   # the NaDiT-3B projections of a 512 x 512 image (M = 1024 tokens): tile-starved
         for r in range(3):
-            for deep in (0, 1):
-                hip.set_option("SVR2_GEMM_DEEP", deep)
-                print(f"SVR2_GEMM_DEEP = {deep}")
-                bench_gemm(1024, 7680, 2560)
-                bench_gemm(1024, 2560, 2560, "gate")
-                bench_gemm(1024, 13824, 2560, "swiglu")
-                bench_gemm(1024, 2560, 6912, "gate")
-                bench_gemm(58, 2560, 2560, "gate")
-        hip.set_option("SVR2_GEMM_DEEP", None)
+            bench_gemm(1024, 7680, 2560)
+            bench_gemm(1024, 2560, 2560, "gate")
+            bench_gemm(1024, 13824, 2560, "swiglu")
+            bench_gemm(1024, 2560, 6912, "gate")
+            bench_gemm(58, 2560, 2560, "gate")
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
-        vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,2,3").split(","))
+        vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
         if os.environ.get("SVR2_KB_ATTN_7B"):
             bench_attn_ab((6, 135, 240), 24, vers, rounds=1)
