@@ -170,7 +170,13 @@ def mid_attention(p, name, x, cfg):
     tok = h.permute(1, 2, 3, 0).reshape(T, H * W, C)
     lin = lambda t, l: F.linear(t, p[f"{name}.{l}.weight"].to(t.dtype), p[f"{name}.{l}.bias"].to(t.dtype))
     q, k, v = lin(tok, "to_q"), lin(tok, "to_k"), lin(tok, "to_v")
-    a = torch.softmax((q @ k.transpose(1, 2)).float() / math.sqrt(C), dim=-1).to(q.dtype) @ v
+    sdpa = lambda q_, k_, v_: torch.softmax((q_ @ k_.transpose(1, 2)).float() / math.sqrt(C), dim=-1).to(q_.dtype) @ v_
+    if T > 1 and H * W > 16384:
+        # frames attend independently: at 4K (129 600 tokens, 67 GB of fp32 scores per frame) the frames of a chunk are
+        # walked one at a time - the same per-frame arithmetic, bounded memory
+        a = torch.cat([sdpa(q[t:t + 1], k[t:t + 1], v[t:t + 1]) for t in range(T)], dim=0)
+    else:
+        a = sdpa(q, k, v)
     o = lin(a, "to_out.0").reshape(T, H, W, C).permute(3, 0, 1, 2)
     return o + res
 
