@@ -140,6 +140,7 @@ struct Attn5Args {
     float scale_log2;
 };
 
+template <int PIPE>
 __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,12 +164,17 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
         char* sV = smem + (2 + stage) * KV5_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int key = wave * 4 + i;
-            int kr = t * KB5 + key;
+            const int key = wave * 4 + i;                         // wave-uniform: the row base below lives in SGPRs,
+            int kr = t * KB5 + key;                               // the lane adds only its swizzled 16-byte chunk
             if (kr > len - 1) kr = len - 1;
             const long long row = (s0 + kr) * a.ld;
-            glds16(a.k + row + ((lane ^ (key & 15)) << 3), sK + key * 1024);
-            glds16(a.v + row + ((lane ^ ((key & 7) << 1)) << 3), sV + key * 1024);
+            // the lane's swizzled chunk offset is recomputed per piece (one v_xor + shift): hoisted out of the loop the
+            // eight per-lane 64-bit row pointers cost 16 VGPRs, which the pipelined loops need for their second
+            // fragment group
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            glds16(a.k + row + ((l ^ (key & 15)) << 3), sK + key * 1024);
+            glds16(a.v + row + ((l ^ ((key & 7) << 1)) << 3), sV + key * 1024);
         }
     };
 
@@ -177,14 +183,12 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     for (int dt = 0; dt < 32; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     const int tq = l15 >> 2, tp = l15 & 3;
-    // lane-dependent swizzled offsets (tables of 4 / 8) + compile-time parts folded into ds_read offsets
-    int koff[4], voff[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) koff[j] = l15 * 1024 + (((((j ^ (l15 >> 2)) & 3) << 2) | (kq ^ (l15 & 3))) << 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        voff[j] = (4 * kq + tq) * 1024 + (((((j ^ (4 * kq + tq)) & 7) << 1) | (tp >> 1)) << 4) + (tp & 1) * 8;
-
+    // lane-dependent swizzled offsets.  The swizzle is an XOR of a 2- / 3-bit field with the fragment index j, so
+    // offset(j) = offset(0) ^ (j << 6) for K and ^ (j << 5) for V: ONE register each survives the loop; the tables of 4 / 8
+    // are rebuilt per tile from the tile's stage base (K table live during QK^T only, V table during PV only) and the
+    // compile-time parts are folded into the ds_read offsets
+    const int koff0 = l15 * 1024 + (((((l15 >> 2) & 3) << 2) | (kq ^ (l15 & 3))) << 4);
+    const int voff0 = (4 * kq + tq) * 1024 + (((((4 * kq + tq) & 7) << 1) | (tp >> 1)) << 4) + (tp & 1) * 8;
     const int nt = (len + KB5 - 1) / KB5;
     issue(0, 0);
     for (int t = 0; t < nt; ++t) {
@@ -193,8 +197,42 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
         if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
         const char* sK = smem + (t & 1) * KV5_BYTES;
         const char* sV = smem + (2 + (t & 1)) * KV5_BYTES;
+        int koff[4], voff[8];
+        {
+            int kb = koff0, vb = voff0;
+            asm volatile("" : "+v"(kb), "+v"(vb));     // per tile, not hoisted: 12 registers that the loop cannot spare
+#pragma unroll
+            for (int j = 0; j < 4; ++j) koff[j] = kb ^ (j << 6);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) voff[j] = vb ^ (j << 5);
+        }
 
         f32x4 sacc[2];
+        bf16x8 fa[4], fb[4];                      // PIPE: two rotating fragment groups (K fragments, then V fragments)
+        if constexpr (PIPE) {
+            // software pipeline: the four fragments of group g+1 are requested BEFORE the four MFMAs of group g, so a
+            // group's LDS latency runs under the previous group's 64 matrix cycles (hipcc's own schedule of the plain
+            // loop is read -> s_waitcnt lgkmcnt(0) -> MFMA with two fragment registers: every round trip exposed,
+            // MFMA busy 40.6 % / LDS array 41.8 %, alternating: profiles/r02_attn512)
+            auto load_k = [&](int g, bf16x8* f) {     // group g = (k2 = g >> 2, ks = 4 (g & 3) .. +4)
+                const char* kp = sK + (g >> 2) * 16 * 1024 + (g & 3) * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(kp + koff[j]);
+            };
+            load_k(0, fa);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                bf16x8* cur = (g & 1) ? fb : fa;
+                bf16x8* nxt = (g & 1) ? fa : fb;
+                if (g + 1 < 8) load_k(g + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((g & 3) == 0) sacc[g >> 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sacc[g >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], qf[(g & 3) * 4 + j], sacc[g >> 2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             sacc[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -205,6 +243,7 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
                 sacc[k2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[k2], 0, 0, 0);
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         // lane holds keys 16*k2 + 4*kq + r of query l15
         if (t == nt - 1 && (len % KB5) != 0) {
@@ -243,6 +282,33 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
             }
         l_run += psum;
 
+        auto load_v = [&](int g, bf16x8* f) {         // group g = dt 4g .. 4g+3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dt = g * 4 + j;
+                const char* p0 = sV + voff[dt & 7] + (dt >> 3) * 256;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 16 * 1024));
+                f[j] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        if constexpr (PIPE) {
+            // (the first V group could travel under the softmax arithmetic; requested here it already overlaps the
+            // exp / convert tail, which the compiler schedules after these reads)
+            load_v(0, fa);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                bf16x8* cur = (g & 1) ? fb : fa;
+                bf16x8* nxt = (g & 1) ? fa : fb;
+                if (g + 1 < 8) load_v(g + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    oacc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], pf, oacc[g * 4 + j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int dt = 0; dt < 32; ++dt) {
             const char* p0 = sV + voff[dt & 7] + (dt >> 3) * 256;
@@ -252,6 +318,7 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
             const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
             if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
 
@@ -345,12 +412,16 @@ extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64
                SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
     SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
                "svr2_attn_d512: pointers must be 16-byte aligned");
-    SVR2_SET_MAX_LDS(attn_d512_kernel, ATT5_LDS, "svr2_attn_d512");
+    const bool pipe = svr2::opt(svr2::OPT_ATTN5_V, 1) != 0;    // SVR2_ATTN5_V=0: the plain loops (A/B; same bits)
+    if (pipe) SVR2_SET_MAX_LDS(attn_d512_kernel<1>, ATT5_LDS, "svr2_attn_d512");
+    else SVR2_SET_MAX_LDS(attn_d512_kernel<0>, ATT5_LDS, "svr2_attn_d512");
     Attn5Args a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
     a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_d512_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS,
-                       (hipStream_t)stream, a);
+    if (pipe)
+        hipLaunchKernelGGL(attn_d512_kernel<1>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_d512_kernel<0>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();
     return SVR2_OK;
 }

@@ -123,3 +123,123 @@ def test_groupnorm_constant_and_scale_fullsize(pkg, gpu):
     assert m.abs().max() < 5e-3 and (s - 1).abs().max() < 1e-2
     y2 = hip.groupnorm_silu((x.float() * 4).to(torch.bfloat16), ones, zeros, 32, 1e-6, silu=False).float()
     assert (y2.view_as(y) - y).abs().max() < 2e-2
+
+
+# ----------------------------------------------------------------------------- cfg4 (NaDiT-7B at 4K) shapes
+D7B, H7B, HID7B = 3072, 24, 12288      # [ref: configs_7b/main.yaml; src/models/dit_7b/mlp.py:27-43]
+
+
+def _ulp_close(got, exp, what):
+    """bf16 results that were rounded once from nearly the same fp32 value: at most one bf16 ulp apart."""
+    d = (got.float() - exp.float()).abs()
+    bound = exp.float().abs() * 2.0 ** -7 + 1e-6
+    i = int((d - bound).argmax())
+    assert (d <= bound).all(), f"{what}: worst |d| {float(d.flatten()[i]):.4g} at |exp| {float(exp.float().abs().flatten()[i]):.4g}"
+
+
+def test_gemm_onehot_7b_mlp_in_gelu_fullsize(pkg, gpu):
+    """proj_in of the 7B MLP at 4K: M = 194 400, K = 3072 -> N = 12 288 with the fused GELU(tanh): an output of 2.39 G
+    elements (past 2^31).  One-hot A rows make the accumulator exactly W[n, idx[m]], so the expected value is
+    gelu_tanh(W[:, idx] + b) rounded once; checked on 4 096 rows incl. the first and the very last one."""
+    hip = pkg.hip
+    g = torch.Generator(device=gpu).manual_seed(10)
+    M, N, K = L4K, HID7B, D7B
+    assert M * N > 2 ** 31
+    w = torch.randn(N, K, generator=g, device=gpu).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device=gpu)
+    idx = torch.randint(0, K, (M,), generator=g, device=gpu)
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=gpu)
+    a[torch.arange(M, device=gpu), idx] = 1.0
+    out = hip.gemm(a, hip.pad_weight(w), N, epilogue=hip.EPI_GELU, bias=bias)
+    assert tuple(out.shape) == (M, N)
+    rows = torch.randint(0, M, (4096,), generator=g, device=gpu)
+    rows[:3] = torch.tensor([0, M - 1, M // 2], device=gpu)
+    exp = torch.nn.functional.gelu(w[:, idx[rows]].T.float() + bias, approximate="tanh").to(torch.bfloat16)
+    _ulp_close(out[rows].flatten(), exp.flatten(), "7B proj_in + GELU at M = 194 400")
+    # every row block was written (no tile skipped past the 2^31-element mark): row sums of a strided sample are finite and non-trivial
+    s = out[::997].float().abs().sum(dim=1)
+    assert torch.isfinite(s).all() and (s > 0).all()
+
+
+def test_gemm_onehot_7b_mlp_out_gate_res_fullsize(pkg, gpu):
+    """proj_out of the 7B MLP at 4K: K = 12 288 -> N = 3072 with `resid + gate * (acc + bias)` (AdaSingle 'out' + residual):
+    the longest K loop of the path (192 K-steps).  One-hot rows: acc = W[n, idx[m]] exactly."""
+    hip = pkg.hip
+    g = torch.Generator(device=gpu).manual_seed(11)
+    M, N, K = L4K, D7B, HID7B
+    w = torch.randn(N, K, generator=g, device=gpu).to(torch.bfloat16)
+    bias, gate = torch.randn(N, generator=g, device=gpu), torch.randn(N, generator=g, device=gpu)
+    resid = torch.randn(M, N, generator=g, device=gpu).to(torch.bfloat16)
+    idx = torch.randint(0, K, (M,), generator=g, device=gpu)
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=gpu)
+    a[torch.arange(M, device=gpu), idx] = 1.0
+    out = hip.gemm(a, hip.pad_weight(w), N, epilogue=hip.EPI_GATE_RES, bias=bias, gate=gate, resid=resid)
+    rows = torch.randint(0, M, (4096,), generator=g, device=gpu)
+    rows[:3] = torch.tensor([0, M - 1, M // 2], device=gpu)
+    exp = (resid[rows].float() + gate * (w[:, idx[rows]].T.float() + bias)).to(torch.bfloat16)
+    d = (out[rows].float() - exp.float()).abs()
+    # two fp32 roundings may differ (fma or not) before the single bf16 rounding: one bf16 ulp of the result's magnitude
+    assert (d <= exp.float().abs() * 2.0 ** -7 + 2.0 ** -8 * (resid[rows].float().abs() + 1)).all(), float(d.max())
+
+
+def test_window_attention_softmax_rows_7b_heads_fullsize(pkg, gpu):
+    """The 4K window set with the 7B's 24 heads (softmax rows sum to one: constant V comes back)."""
+    hip, Wn = pkg.hip, pkg.windows
+    H, D, Lt = H7B, 128, 58
+    grid = (6, 135, 240)
+    g = torch.Generator(device=gpu).manual_seed(12)
+    for method in (Wn.REGULAR, Wn.SHIFTED):
+        pl = Wn.plan(grid, method, Lt)
+        S = pl.total
+        up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(gpu)
+        q = torch.randn(S, H, D, generator=g, device=gpu).to(torch.bfloat16)
+        k = torch.randn(S, H, D, generator=g, device=gpu).to(torch.bfloat16)
+        const = torch.randn(H, D, generator=g, device=gpu).to(torch.bfloat16)
+        v = const.expand(S, H, D).contiguous()
+        out = hip.window_attn(q, k, v, up(pl.cu_seqlens), up(pl.tile_seq), up(pl.tile_q0), 1 / math.sqrt(D))
+        err = (out.float() - const.float()).abs().max().item()
+        assert err <= 2 ** -6 * const.float().abs().max().item() + 1e-3, (method, err)
+        del q, k, v, out
+
+
+def test_qkv_prep_7b_rope_fullsize(pkg, gpu):
+    """qkv_prep with 24 heads and the 7B 'pixel' rope (per-position tables, video rows only) on the 4K window set
+    [ref: src/models/dit_7b/rope.py:73-124]: against the same call with identity tables (cos = 1, sin = 0), every rotated
+    pair keeps its norm, the dims beyond the 3 x 10 rotary pairs and all text rows are bit-identical, v is the plain
+    window gather of the input."""
+    hip, Wn = pkg.hip, pkg.windows
+    H, D, Lt = H7B, 128, 58
+    grid = (6, 135, 240)
+    L = grid[0] * grid[1] * grid[2]
+    g = torch.Generator(device=gpu).manual_seed(13)
+    cfg = pkg.dit.CFG_7B
+    model = object.__new__(pkg.dit.NaDiTHip)            # only the table builder is used: no weights
+    model.cfg, model.device, model._rope7 = cfg, gpu, {}
+    qkv_v = torch.randn(L, 3 * H * D, generator=g, device=gpu).to(torch.bfloat16)
+    qkv_t = torch.randn(Lt, 3 * H * D, generator=g, device=gpu).to(torch.bfloat16)
+    ones = torch.ones(D, device=gpu)
+    up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(gpu)
+    for method in (Wn.REGULAR, Wn.SHIFTED):
+        pl = Wn.plan(grid, method, Lt)
+        S = pl.total
+        rc, rs = model._rope_tables_7b(grid, method, Lt)
+        assert tuple(rc.shape) == (S, 30)
+        src, pos = up(pl.src_row), up(pl.pos)
+        rot = hip.qkv_prep(qkv_v, qkv_t, src, pos, ones, ones, ones, ones, rc, rs, H, 2, 1e-5)
+        idn = hip.qkv_prep(qkv_v, qkv_t, src, pos, ones, ones, ones, ones, torch.ones_like(rc), torch.zeros_like(rs), H, 2, 1e-5)
+        is_txt = src < 0
+        assert int(is_txt.sum()) == pl.nwin * Lt
+        assert torch.equal(rot[2], idn[2])                                  # v: no rope
+        vid_rows = (~is_txt).nonzero().flatten()
+        assert torch.equal(rot[2][vid_rows[:4096]].reshape(4096, -1), qkv_v[src[vid_rows[:4096]].long(), 2 * H * D:])
+        for o in (0, 1):
+            assert torch.equal(rot[o][is_txt], idn[o][is_txt])              # text rows are not rotated
+            assert torch.equal(rot[o][:, :, 60:], idn[o][:, :, 60:])        # 3 axes x 10 freqs x 2 = 60 rotary dims
+            sel = vid_rows[torch.randint(0, vid_rows.numel(), (20000,), generator=g, device=gpu)]
+            sel[:2] = torch.stack((vid_rows[0], vid_rows[-1]))
+            a = rot[o][sel][:, :, :60].float().reshape(-1, H, 30, 2)
+            b = idn[o][sel][:, :, :60].float().reshape(-1, H, 30, 2)
+            na, nb = a.pow(2).sum(-1).sqrt(), b.pow(2).sum(-1).sqrt()
+            assert ((na - nb).abs() <= 2.0 ** -6 * nb + 1e-3).all()          # both sides carry one bf16 rounding per element
+            assert (a - b).abs().max() > 0.1                                 # ... and the rotation is not the identity
+        del rot, idn

@@ -7,13 +7,20 @@ DiT grid (3,68,120).
 Reference path being matched: src/core/generation_phases.py:342-521,650-753,904-1026,
 src/core/infer.py:117-257, src/models/dit_3b/nadit.py:190-248 (dit_7b/nadit.py for the 7B).
 
-Tolerances (floating point; stated here): the reference's own CPU path computes in bf16 op by op
-(optimization/compatibility.py:207-221) and therefore deviates from exact arithmetic by e_bf16 =
-|oracle_bf16 - oracle_fp32|.  The HIP path (bf16 storage, fp32 accumulation) must satisfy, per stage,
-    rel_rms(hip, fp32) <= 2 * rel_rms(bf16 oracle, fp32) + 2e-3
-and on the decoded RGB in [0,1]
-    PSNR(hip, fp32) >= PSNR(bf16 oracle, fp32) - 3 dB   and   PSNR(hip, bf16 oracle) >= PSNR(fp32, bf16 oracle) - 3 dB
-i.e. the HIP result is as close to either flavour of the reference as they are to each other.
+Tolerances (floating point; stated here, defined in DESIGN section 6).  The reference's own CPU path computes in bf16 op
+by op (optimization/compatibility.py:207-221) and therefore deviates from exact arithmetic (the fp32 oracle) by
+e_bf16 = |oracle_bf16 - oracle_fp32|.  The HIP path (bf16 storage, fp32 accumulation) must satisfy
+
+  T1  the north star's literal gate: an HR image / clip is synthesised, degraded to the LR input (antialiased bicubic x1/2,
+      8-bit quantisation), upscaled by the HIP path and by the bf16 oracle (= the reference's CPU path):
+          | PSNR(hip, HR) - PSNR(bf16 oracle, HR) | <= 0.01 dB
+  T2  no farther from exact arithmetic than the reference's CPU path:
+          PSNR(hip, fp32 oracle) >= PSNR(bf16 oracle, fp32 oracle) - 0.01 dB
+      and per stage (latent, x0)  rel_rms(hip, fp32) <= 1.02 * rel_rms(bf16 oracle, fp32)
+  T3  direct distance to the reference's CPU path: PSNR(hip, bf16 oracle) >= 41.5 dB, max-abs <= 0.0625 on RGB in [0,1]
+      (measured 42.0 - 44.5 dB; the two are independent bf16 roundings of the same arithmetic, each ~44 - 45.7 dB from exact)
+  T4  regression guard: rel_rms(hip, fp32) per stage <= 1.1 x the value recorded in profiles/r03_fullwidth_parity.json.
+
 The measured numbers are written to gpurun_out/fullwidth_parity.json (BASELINE.md section 4 / DESIGN section 6).
 """
 
@@ -48,12 +55,44 @@ def _record(name, row):
         json.dump(data, fh, indent=1)
 
 
-def _lr_image(seed=1234):
-    """SURVEY 8d synthetic input: smooth seeded content, uint8-quantised then /255 like the CLI."""
+def _hr_lr(n, H, W, seed):
+    """(HR [n,H,W,3] in [0,1], LR [n,H/2,W/2,3]): seeded smooth content plus fine detail as the HR truth, degraded to the
+    LR input by an antialiased bicubic x1/2 and the CLI's 8-bit quantisation (uint8 / 255, inference_cli.py:543)."""
     g = torch.Generator().manual_seed(seed)
-    low = 0.5 + 0.2 * torch.randn(1, 3, 16, 16, generator=g)
-    x = torch.nn.functional.interpolate(low, size=(256, 256), mode="bicubic", align_corners=False).clamp(0, 1)
-    return ((x * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
+    low = 0.5 + 0.2 * torch.randn(n, 3, max(H // 32, 2), max(W // 32, 2), generator=g)
+    hr = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)
+    hr = (hr + 0.03 * torch.randn(n, 3, H, W, generator=g)).clamp(0, 1)
+    lr = torch.nn.functional.interpolate(hr, size=(H // 2, W // 2), mode="bicubic", align_corners=False, antialias=True).clamp(0, 1)
+    lr = (lr * 255).round() / 255
+    return hr.permute(0, 2, 3, 1).contiguous(), lr.permute(0, 2, 3, 1).contiguous()
+
+
+def _recorded():
+    """Last committed measurements of these very tests (regression guard T4); None before the first record exists."""
+    for name in ("r03_fullwidth_parity.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh)
+    return {}
+
+
+def _rgb_gates(tag, got, ref32, ref16, hr, maxabs=0.0625):
+    """T1 - T3 on decoded RGB in [0,1]; returns the measured row."""
+    p_hip32, p_b16, p_hip16 = psnr(got, ref32), psnr(ref16, ref32), psnr(got, ref16)
+    p_hip_hr, p_or_hr = psnr(got, hr), psnr(ref16, hr)
+    row = dict(psnr_hip_vs_fp32=p_hip32, psnr_bf16oracle_vs_fp32=p_b16, psnr_hip_vs_bf16oracle=p_hip16,
+               psnr_hip_vs_hr=p_hip_hr, psnr_bf16oracle_vs_hr=p_or_hr, psnr_fp32oracle_vs_hr=psnr(ref32, hr),
+               maxabs_hip_vs_fp32=float((got - ref32).abs().max()),
+               maxabs_bf16oracle_vs_fp32=float((ref16 - ref32).abs().max()),
+               maxabs_hip_vs_bf16oracle=float((got - ref16).abs().max()))
+    print(f"[{tag}] decoded RGB: PSNR vs HR hip {p_hip_hr:.4f} dB / bf16 oracle {p_or_hr:.4f} dB (T1: |d| = {abs(p_hip_hr - p_or_hr):.4f}); "
+          f"vs fp32 oracle hip {p_hip32:.2f} / bf16 oracle {p_b16:.2f} dB (T2); hip vs bf16 oracle {p_hip16:.2f} dB, "
+          f"max|d| {row['maxabs_hip_vs_bf16oracle']:.4f} (T3)")
+    assert abs(p_hip_hr - p_or_hr) <= 0.01, (tag, "T1", p_hip_hr, p_or_hr)
+    assert p_hip32 >= p_b16 - 0.01, (tag, "T2", p_hip32, p_b16)
+    assert p_hip16 >= 41.5 and row["maxabs_hip_vs_bf16oracle"] <= maxabs, (tag, "T3", p_hip16, row["maxabs_hip_vs_bf16oracle"])
+    return row
 
 
 def _cpu_params(sd):
@@ -79,7 +118,7 @@ def test_cfg1_end_to_end_full_width(pkg, gpu, model):
     del vsd, dsd
     txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).float()
     pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
-    lr = _lr_image()
+    hr, lr = _hr_lr(1, 512, 512, 1234)
 
     # HIP path: the product's generate() for the RGB, and the same stages one by one for the taps
     got = pipe.generate(lr, resolution=512, batch_size=1, temporal_overlap=0, seed=42, color_correction="none").float().cpu()
@@ -99,7 +138,8 @@ def test_cfg1_end_to_end_full_width(pkg, gpu, model):
                                     rope_mode=rope).float()
         print(f"[{model}] oracle {name}: {time.time() - t0:.1f}s on {torch.get_num_threads()} threads")
 
-    row = {"model": model, "input": "[1,256,256,3] -> 512x512, seed 42, color_correction none"}
+    row = {"model": model, "input": "HR [1,512,512,3] degraded to [1,256,256,3] -> 512x512, seed 42, color_correction none"}
+    rec = _recorded().get(f"cfg1_{model}", {})
     for stage in ("latent", "x0"):
         e_hip = _rel(hip_taps[stage], taps["fp32"][stage])
         e_b16 = _rel(taps["bf16"][stage], taps["fp32"][stage])
@@ -108,18 +148,12 @@ def test_cfg1_end_to_end_full_width(pkg, gpu, model):
         row[f"{stage}_rel_rms_hip_vs_bf16oracle"] = _rel(hip_taps[stage], taps["bf16"][stage])
         print(f"[{model}] {stage}: rel-rms hip vs fp32 {e_hip:.3e}; bf16 oracle vs fp32 {e_b16:.3e}")
         assert torch.isfinite(hip_taps[stage]).all()
-        assert e_hip <= 2.0 * e_b16 + 2e-3, (stage, e_hip, e_b16)
-    p_hip32, p_b16 = psnr(got, refs["fp32"]), psnr(refs["bf16"], refs["fp32"])
-    p_hip16 = psnr(got, refs["bf16"])
-    row.update(psnr_hip_vs_fp32=p_hip32, psnr_bf16oracle_vs_fp32=p_b16, psnr_hip_vs_bf16oracle=p_hip16,
-               maxabs_hip_vs_fp32=float((got - refs["fp32"]).abs().max()),
-               maxabs_bf16oracle_vs_fp32=float((refs["bf16"] - refs["fp32"]).abs().max()),
-               maxabs_hip_vs_bf16oracle=float((got - refs["bf16"]).abs().max()),
-               seconds=time.time() - t_all, cpu_threads=torch.get_num_threads())
-    print(f"[{model}] decoded RGB: PSNR hip vs fp32 {p_hip32:.2f} dB (bf16 oracle vs fp32 {p_b16:.2f} dB), hip vs bf16 oracle "
-          f"{p_hip16:.2f} dB; max|d| {row['maxabs_hip_vs_fp32']:.4f} (bf16 oracle {row['maxabs_bf16oracle_vs_fp32']:.4f})")
+        assert e_hip <= 1.02 * e_b16, (stage, "T2", e_hip, e_b16)
+        if f"{stage}_rel_rms_hip_vs_fp32" in rec:
+            assert e_hip <= 1.1 * rec[f"{stage}_rel_rms_hip_vs_fp32"], (stage, "T4", e_hip, rec[f"{stage}_rel_rms_hip_vs_fp32"])
+    row.update(_rgb_gates(model, got, refs["fp32"], refs["bf16"], hr))
+    row.update(seconds=time.time() - t_all, cpu_threads=torch.get_num_threads())
     _record(f"cfg1_{model}", row)
-    assert p_hip32 >= p_b16 - 3.0 and p_hip16 >= p_b16 - 3.0 and p_hip32 > 30.0
 
 
 def test_video_end_to_end_full_width_3b(pkg, gpu):
@@ -136,12 +170,9 @@ def test_video_end_to_end_full_width_3b(pkg, gpu):
     del vsd, dsd
     txt = (0.5 * torch.randn(58, 5120, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).float()
     pipe = pkg.pipeline.SeedVR2Pipeline(vae, dit, txt, gpu)
-    g = torch.Generator().manual_seed(77)
-    low = 0.5 + 0.2 * torch.randn(9, 3, 8, 12, generator=g)
-    lr = torch.nn.functional.interpolate(low, size=(64, 96), mode="bicubic", align_corners=False).clamp(0, 1)
-    lr = ((lr * 255).round() / 255).permute(0, 2, 3, 1).contiguous()
+    hr, lr = _hr_lr(9, 128, 192, 77)
     kw = dict(resolution=128, batch_size=5, temporal_overlap=2, seed=42)
-    row = {"input": "[9,64,96,3] -> 128x192, batch_size 5, temporal_overlap 2, seed 42"}
+    row = {"input": "HR [9,128,192,3] degraded to [9,64,96,3] -> 128x192, batch_size 5, temporal_overlap 2, seed 42"}
     modes = ("none", "lab")
     t0 = time.time()
     # the oracle's models run once per dtype; its phase 4 is applied per colour-correction mode to that one pass
@@ -152,13 +183,10 @@ def test_video_end_to_end_full_width_3b(pkg, gpu):
         got = pipe.generate(lr, color_correction=cc, **kw).float().cpu()
         ref32, ref16 = refs32[cc].float(), refs16[cc].float()
         assert got.shape == ref32.shape == (9, 128, 192, 3)
-        p_hip, p_b16, p_hb = psnr(got, ref32), psnr(ref16, ref32), psnr(got, ref16)
-        print(f"video full width (color_correction={cc}): PSNR hip vs fp32 {p_hip:.2f} dB (bf16 oracle vs fp32 {p_b16:.2f} dB), "
-              f"hip vs bf16 oracle {p_hb:.2f} dB, max|d| {float((got - ref32).abs().max()):.4f}; oracle {t_or:.0f}s")
-        row[cc] = {"psnr_hip_vs_fp32": p_hip, "psnr_bf16oracle_vs_fp32": p_b16, "psnr_hip_vs_bf16oracle": p_hb,
-                   "maxabs_hip_vs_fp32": float((got - ref32).abs().max()),
-                   "maxabs_bf16oracle_vs_fp32": float((ref16 - ref32).abs().max())}
-        assert p_hip >= p_b16 - 3.0 and p_hb >= p_b16 - 3.0 and p_hip > 30.0
+        # `lab` transfers histograms by rank: a tie broken differently moves single pixels by a few levels (the bf16 oracle
+        # itself is 0.10 from the fp32 one there), so its max-abs bound is wider; the PSNR gates are the same
+        row[cc] = _rgb_gates(f"video9 {cc}", got, ref32, ref16, hr, maxabs=0.0625 if cc == "none" else 0.15)
+        row[cc]["oracle_seconds"] = t_or
     _record("video9_3b", row)
 
 
@@ -190,4 +218,7 @@ def test_dit_full_width_cfg2_grid(pkg, gpu):
                                         "rel_rms_bf16oracle_vs_fp32": e_b16, "rel_rms_hip_vs_bf16oracle": _rel(got, ref16),
                                         "maxabs_over_rms_hip": float((got - ref32).abs().max() / ref32.pow(2).mean().sqrt())})
     assert torch.isfinite(got).all()
-    assert e_hip <= 2.0 * e_b16 + 2e-3
+    assert e_hip <= 1.02 * e_b16, ("T2", e_hip, e_b16)
+    rec = _recorded().get("dit_fullwidth_cfg2_grid", {})
+    if "rel_rms_hip_vs_fp32" in rec:
+        assert e_hip <= 1.1 * rec["rel_rms_hip_vs_fp32"], ("T4", e_hip, rec["rel_rms_hip_vs_fp32"])

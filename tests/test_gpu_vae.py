@@ -70,6 +70,18 @@ def test_attn_d512(pkg, gpu, frames, P):
     assert_close(out.reshape(frames, P, 512), ref, "attn_d512", rtol=2e-2, atol_rel=2e-2)
 
 
+def test_attn_d512_pipelined_equals_plain_loops(pkg, gpu, lib_option):
+    """The software-pipelined fragment schedule (default) only reorders LDS reads against MFMAs: same bits as the plain
+    loops (SVR2_ATTN5_V=0), ragged last tile and rescale path included."""
+    qkv = rnd(2 * 333, 1536, seed=6)
+    qkv[7, 512:1024] = qkv[3, :512] * 2.0
+    x = dev_bf16(qkv, gpu)
+    piped = pkg.hip.attn_d512(x, 2, 333)
+    lib_option("SVR2_ATTN5_V", 0)
+    plain = pkg.hip.attn_d512(x, 2, 333)
+    assert torch.equal(piped, plain)
+
+
 def test_resize_pad_normalize(pkg, gpu):
     from seedvr2_ref import pipeline as opipe
     P = pkg.pipeline

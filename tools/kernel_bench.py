@@ -112,9 +112,13 @@ def bench_attn_ab(grid, H=20, versions=(1, 2, 3), rounds=3):
 def bench_attn512(frames, P):
     qkv = rb(frames * P, 1536)
     out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
-    for var in ("v16",):
-        t = timeit(lambda: hip.attn_d512(qkv, frames, P, out), iters=3, warm=1)
-        print(f"attn_d512[{var}] frames={frames} P={P}: {t*1e3:.3f} ms  {4*512*P*P*frames/t/1e12:.1f} TFLOP/s", flush=True)
+    # same-process A/B, interleaved: SVR2_ATTN5_V 0 = plain loops, 1 = software-pipelined fragment groups (default)
+    for rnd in range(3):
+        for var in (0, 1):
+            hip.set_option("SVR2_ATTN5_V", var)
+            t = timeit(lambda: hip.attn_d512(qkv, frames, P, out), iters=3, warm=1)
+            print(f"attn_d512[SVR2_ATTN5_V={var}] frames={frames} P={P}: {t*1e3:.3f} ms  {4*512*P*P*frames/t/1e12:.1f} TFLOP/s", flush=True)
+    hip.set_option("SVR2_ATTN5_V", None)
 
 
 def bench_norm(rows, dim):
