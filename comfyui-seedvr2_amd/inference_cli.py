@@ -254,6 +254,8 @@ def fan_out(devs: List[str], argv: List[str], rt: Runtime) -> int:
         for i in range(len(devs)):
             env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(len(devs)), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            # the ranks share the host cores (CPU-generator noise, reader / writer threads) instead of oversubscribing them
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or len(devs)) // len(devs))))
             procs.append(subprocess.Popen(rt.child_cmd + list(argv), env=env))
         while any(p.poll() is None for p in procs):
             bad = [p for p in procs if p.poll() not in (None, 0)]

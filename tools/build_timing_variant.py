@@ -9,6 +9,7 @@ A/B switch SVR2_LIB names another file (hip.lib() then says so on stderr).
 
     python tools/build_timing_variant.py gemm4 SVR2_G4_DBG=1      # no DMA in the K loop
     python tools/build_timing_variant.py conv_halo SVR2_HALO_DBG=1 # conv_halo_wr without epilogue
+    python tools/build_timing_variant.py conv_halo_gnfuse SVR2_HALO_GNFUSE=1   # + the LDS/VALU work of a fused GroupNorm+SiLU
     SVR2_LIB=build/timing/gemm4_SVR2_G4_DBG_1/libseedvr2_hip.so python tools/kernel_bench.py gemm
 """
 import glob
@@ -30,7 +31,9 @@ def build(variant: str, macro: str) -> str:
     shutil.rmtree(os.path.join(work, "..", "include"), ignore_errors=True)       # common.h includes ../../include/seedvr2_hip.h
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "..", "include"))
     patch = os.path.join(ROOT, "tools", "timing_variants", f"{variant}_dbg.patch")
-    subprocess.check_call(["patch", "-s", os.path.join(work, "csrc", f"{variant}.hip"), patch])
+    with open(patch) as fh:
+        target = fh.readline().split()[1]          # "--- conv_halo.hip <date>": the source the patch applies to
+    subprocess.check_call(["patch", "-s", os.path.join(work, "csrc", os.path.basename(target)), patch])
     objs = []
     for s in sorted(glob.glob(os.path.join(work, "csrc", "*.hip"))):
         o = os.path.join(work, os.path.basename(s) + ".o")
