@@ -295,6 +295,42 @@ def test_window_attn(pkg, gpu, lens, H):
     assert_close(out, attn_ref(q, k, v, lens), f"window_attn {lens}", rtol=2e-2, atol_rel=2e-2)
 
 
+def test_qkv_prep_is_bit_stable_beside_the_128_row_gemm_on_a_second_stream(pkg, gpu):
+    """Regression for profiles/r02_concurrency: with hipcc's packed-f32 forms qkv_prep returned a wrong low half of one
+    v_pk_fma_f32 of the rope rotation in 40 % of its calls whenever gemm_kernel<..,128> ran on the same CUs (a second
+    stream of the same process is enough).  The build emits no packed-f32 instruction (checked on the shipped library by
+    tests/test_cpu_host.py); here the condition itself: 3 000 calls beside the GEMM, every one equal to the first."""
+    hip, Wn = pkg.hip, pkg.windows
+    H, grid, Lt = 20, (2, 3, 4), 58
+    g = torch.Generator().manual_seed(1)
+    pl = Wn.plan(grid, Wn.REGULAR, Lt)
+    L = grid[0] * grid[1] * grid[2]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    qkv_v = torch.randn(L, 3 * H * 128, generator=g).to(torch.bfloat16).to(gpu)
+    qkv_t = torch.randn(Lt, 3 * H * 128, generator=g).to(torch.bfloat16).to(gpu)
+    qn, kn = (1 + 0.1 * torch.randn(128, generator=g)).to(gpu), (1 + 0.1 * torch.randn(128, generator=g)).to(gpu)
+    fr = 1.0 / (10000.0 ** (torch.arange(0, 42, 2)[:21].float() / 42))
+    ang = torch.arange(1024, dtype=torch.float32)[:, None] * fr[None]
+    rc, rs = ang.cos().contiguous().to(gpu), ang.sin().contiguous().to(gpu)
+    src, pos = up(pl.src_row), up(pl.pos)
+    ga = torch.randn(24, 2560, device=gpu).to(torch.bfloat16)
+    gw = hip.pad_weight((torch.randn(7680, 2560, device=gpu) * 0.02).to(torch.bfloat16))
+    gout = torch.empty(24, 7680, dtype=torch.bfloat16, device=gpu)
+    side = torch.cuda.Stream()
+    for mode, c, s_ in ((1, rc, rs), (2, torch.rand(pl.total, 30, generator=g).to(gpu), torch.rand(pl.total, 30, generator=g).to(gpu))):
+        call = lambda: hip.qkv_prep(qkv_v, qkv_t, src, pos, qn, kn, qn, kn, c, s_, H, mode, 1e-5)
+        ref = call().clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for i in range(1500):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    hip.gemm(ga, gw, 7680, gout)
+            bad += int(not torch.equal(call(), ref))
+        torch.cuda.synchronize()
+        assert bad == 0, f"rope_mode {mode}: {bad} of 1500 qkv_prep calls differ beside the 128-row GEMM"
+
+
 def test_window_attn_default_kernel_bit_identical_to_plain_kernel(pkg, gpu, lib_option):
     """flash_attn2_kernel (default) and the plain flash_attn_kernel of the same tile geometry (SVR2_ATTN_V=1) share the
     summation order: equal bits on ragged sequences incl. the rescale spike - the only reason the switch still exists."""
