@@ -338,200 +338,6 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     }
 }
 
-// ---- d-split pairs (default for the VAE mid-block attention).  Why: in attn_d512_kernel every wave owns 16 queries x all
-// 512 dims and therefore re-reads the whole K and V tile from LDS (1 KiB per 16-cycle MFMA: the LDS array and the MFMA pipe
-// need the same 2 048 cycles per tile, measured 41 % / 42 % busy, alternating: profiles/r02_attn512).  Here a PAIR of waves
-// (w, w + 4: the two waves of one SIMD) owns 32 queries; each wave of the pair holds half of the head dimension (256 dims:
-// Q 64 registers, O^T 128) and uses v_mfma_f32_32x32x16_bf16 in the swapped orientation of attn.hip:
-//     S^T_half[key][query] = K[:, half] . Q[:, half]^T          (16 MFMAs, A = K fragments of the wave's half: 16 KiB of LDS)
-//     S^T = S^T_half + partner's S^T_half                       (4 KiB written + 4 KiB read per wave through LDS, one barrier)
-//     softmax per lane (both waves of the pair compute the same P^T, bit for bit: a + b == b + a)
-//     O^T_half[d][query] += V^T[half] . P^T                     (16 MFMAs, V^T by ds_read_b64_tr_b16: 16 KiB of LDS)
-// 40 KiB of LDS traffic per wave and tile instead of 64 for twice the queries per wave: 1 280 LDS cycles per 2 048 MFMA
-// cycles and tile.  Two waves per SIMD and eight DMA pieces per wave and tile as before.  LDS images: 1 024-byte rows (one
-// key), K chunk ^= key & 15, V chunk ^= (key & 3) << 2 (the images of attn.hip's kernel: rows of 256 and of 1 024 bytes alias
-// the same way on the 64 banks), fragment groups requested one group ahead of their MFMAs.
-constexpr int XB5 = 8 * 4096;                         // S^T exchange, 4 KiB per wave
-constexpr int ATT5DS_LDS = 4 * KV5_BYTES + XB5;       // 160 KiB: the whole LDS of a CU
-
-__global__ __launch_bounds__(NTH5) void attn_d512_ds_kernel(const Attn5Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = wave & 3, dh = wave >> 2;              // 32-query block of the pair, half of the head dimension
-    const int l31 = lane & 31, hh = lane >> 5;
-    const long long s0 = (long long)blockIdx.y * a.P;
-    const int q0 = blockIdx.x * QB5;
-    const int len = a.P;
-
-    bf16x8 qf[16];                                         // B operand of S^T = K . Q^T: lane = (query l31, k-half hh)
-    {
-        int qr = q0 + qb * 32 + l31;
-        if (qr > len - 1) qr = len - 1;
-        const bf16* qp = a.q + (s0 + qr) * a.ld + dh * 256 + hh * 8;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
-    auto issue = [&](int t, int stage) {
-        char* sK = smem + stage * KV5_BYTES;
-        char* sV = smem + (2 + stage) * KV5_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = wave * 4 + i;                  // wave-uniform row; the lane adds its swizzled 16-byte chunk
-            int kr = t * KB5 + key;
-            if (kr > len - 1) kr = len - 1;
-            const long long row = (s0 + kr) * a.ld;
-            int l = lane;
-            asm volatile("" : "+v"(l));                    // per piece, not hoisted (16 VGPRs of row pointers otherwise)
-            glds16(a.k + row + ((l ^ (key & 15)) << 3), sK + key * 1024);
-            glds16(a.v + row + ((l ^ ((key & 3) << 2)) << 3), sV + key * 1024);
-        }
-    };
-
-    f32x16 oacc[8];
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c = a.scale_log2;
-    const int tg = (lane >> 4) & 1, ti = lane & 15;
-    const int tq = ti >> 2, tp = ti & 3;
-    // offset(j) = offset(0) ^ (j << 5) for K (j = k-step & 7) and ^ (j << 6) for V (j = d-tile & 3): one register each
-    const int koff0 = l31 * 1024 + dh * 512 + (((((l31 >> 1) & 7) << 1) | (hh ^ (l31 & 1))) << 4);
-    const int voff0 = (4 * hh + tq) * 1024 + dh * 512 + (((tq << 2) | (2 * tg) | (tp >> 1)) << 4) + (tp & 1) * 8;
-    char* const xmine = smem + 4 * KV5_BYTES + wave * 4096 + lane * 16;
-    const char* const xpart = smem + 4 * KV5_BYTES + (wave ^ 4) * 4096 + lane * 16;
-
-    const int nt = (len + KB5 - 1) / KB5;
-    issue(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        const char* sK = smem + (t & 1) * KV5_BYTES;
-        const char* sV = smem + (2 + (t & 1)) * KV5_BYTES;
-        int kb = koff0, vb = voff0;
-        asm volatile("" : "+v"(kb), "+v"(vb));             // the tables below are rebuilt per tile (live in one phase each)
-
-        // ---- S^T_half = K[:, half] . Q[:, half]^T: 16 k-steps, fragment pairs requested one pair ahead
-        f32x16 sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        {
-            bf16x8 fa[2], fb[2];
-            auto load_k = [&](int g, bf16x8* f) {          // pair g = k-steps 2g, 2g + 1
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int ks = 2 * g + j;
-                    f[j] = *(const bf16x8*)(sK + (kb ^ ((ks & 7) << 5)) + (ks >> 3) * 256);
-                }
-            };
-            load_k(0, fa);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                bf16x8* cur = (g & 1) ? fb : fa;
-                bf16x8* nxt = (g & 1) ? fa : fb;
-                if (g + 1 < 8) load_k(g + 1, nxt);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[j], qf[2 * g + j], sacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- S^T = own half + partner's half (same lane layout in both waves: an element-wise add)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4)
-            *(f32x4*)(xmine + r4 * 1024) = f32x4{sacc[4 * r4], sacc[4 * r4 + 1], sacc[4 * r4 + 2], sacc[4 * r4 + 3]};
-        __syncthreads();
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 o = *(const f32x4*)(xpart + r4 * 1024);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sacc[4 * r4 + e] += o[e];
-        }
-
-        // lane holds keys 4 hh + (r & 3) + 8 (r >> 2) of query l31
-        if (t == nt - 1 && (len % KB5) != 0) {
-            const int kbase = t * KB5 + 4 * hh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kbase + (r & 3) + 8 * (r >> 2) >= len) sacc[r] = -INFINITY;
-        }
-        float mx = sacc[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > 4.0f) != 0) {   // deferred rescale (see attn.hip)
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-        }
-        const float mc = m_run * c;
-        float psum = 0.f;
-        bf16x8 pf[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c, -mc));
-            psum += p;
-            pf[r >> 3][r & 7] = f2bf(p);
-        }
-        l_run += psum;
-
-        // ---- O^T_half += V^T[half] . P^T: two 16-key steps x eight 32-dim tiles, tile pairs requested one pair ahead
-        {
-            bf16x8 fa[2], fb[2];
-            auto load_v = [&](int g, bf16x8* f) {          // pair g = (key step g >> 2, d-tiles 2 (g & 3), 2 (g & 3) + 1)
-                const char* vrow = sV + (g >> 2) * 16 * 1024 + ((g >> 1) & 1) * 256;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const char* p0 = vrow + (vb ^ ((2 * (g & 1) + j) << 6));
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 8 * 1024));
-                    f[j] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            };
-            load_v(0, fa);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                bf16x8* cur = (g & 1) ? fb : fa;
-                bf16x8* nxt = (g & 1) ? fa : fb;
-                if (g + 1 < 8) load_v(g + 1, nxt);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int dt = 2 * (g & 3) + j;
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[j], pf[g >> 2], oacc[dt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qr = q0 + qb * 32 + l31;
-    if (qr < len) {
-        bf16* op = a.out + (s0 + qr) * a.ldo + dh * 256 + 4 * hh;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[dt][g * 4 + e] * inv);
-                *(bf16x4*)(op + dt * 32 + g * 8) = o;
-            }
-    }
-}
-
 inline int gn_blocks(long long P, int C) {
     const int ppb = 256 / (C >> 3);
     long long nb = (P + (long long)ppb * 8 - 1) / ((long long)ppb * 8);
@@ -606,18 +412,19 @@ extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64
                SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
     SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
                "svr2_attn_d512: pointers must be 16-byte aligned");
-    // SVR2_ATTN5_V: 2 (default) = d-split wave pairs on 32x32x16 MFMAs; 1 = 16-query waves with the software-pipelined
-    // fragment schedule; 0 = 16-query waves, plain loops (0 and 1 give the same bits; 2 differs by fp32 summation order)
-    const int ver = svr2::opt(svr2::OPT_ATTN5_V, 2);
-    if (ver == 2) SVR2_SET_MAX_LDS(attn_d512_ds_kernel, ATT5DS_LDS, "svr2_attn_d512");
-    else if (ver == 1) SVR2_SET_MAX_LDS(attn_d512_kernel<1>, ATT5_LDS, "svr2_attn_d512");
+    // SVR2_ATTN5_V: 1 (default) = the software-pipelined fragment schedule; 0 = the plain loops (A/B; same bits).
+    // A third form - pairs of waves that split the head dimension (32 queries per pair on 32x32x16 MFMAs, S^T halves
+    // exchanged through LDS: 40 instead of 64 KiB of LDS reads per wave and tile) - was built, parity-green and SLOWER
+    // (923 vs 1 063 TFLOP/s at 129 600 tokens, profiles/r03_attn512): the kernel is bound by the K/V delivery into LDS
+    // plus reads plus MFMAs in series, not by the LDS reads alone, and the exchange barrier and the duplicated softmax
+    // cost more than the reads they save.  Removed; the code is in the history (the commit before this comment).
+    const int ver = svr2::opt(svr2::OPT_ATTN5_V, 1);
+    if (ver == 1) SVR2_SET_MAX_LDS(attn_d512_kernel<1>, ATT5_LDS, "svr2_attn_d512");
     else SVR2_SET_MAX_LDS(attn_d512_kernel<0>, ATT5_LDS, "svr2_attn_d512");
     Attn5Args a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
     a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;
-    if (ver == 2)
-        hipLaunchKernelGGL(attn_d512_ds_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5DS_LDS, (hipStream_t)stream, a);
-    else if (ver == 1)
+    if (ver == 1)
         hipLaunchKernelGGL(attn_d512_kernel<1>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(attn_d512_kernel<0>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);

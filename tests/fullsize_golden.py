@@ -237,5 +237,28 @@ elif CASE == "vae4k_dec":
     compare("dec", got, "dec", 64, peak=2.0)
     meta["psnr_full_hip_vs_oracle_pm1"] = fc.psnr(got, ref, peak=2.0)
     finish()
+elif CASE == "aten_check":
+    # the piecewise ATen-on-GPU executor of the oracle's decoder against the plain CPU oracle (fp32) at a size the CPU
+    # finishes in minutes: 2 latent frames of 68 x 120 -> 5 frames of 544 x 960, pieces capped at 2^24 elements so that every
+    # full-resolution conv is cut into strips like the 4K run cuts them
+    import aten_oracle
+    vp = {k: v.to(torch.bfloat16).float() for k, v in ovae.synthetic_params(ovae.VAEConfig(), 1).items() if k.startswith("decoder.")}
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(2, 68, 120, 16, generator=g).to(torch.bfloat16)
+    t0 = time.time()
+    with torch.no_grad():
+        ref = ovae.decode(vp, z, ovae.VAEConfig(), torch.float32).permute(1, 2, 3, 0).contiguous()
+    meta["cpu_fp32_seconds"] = time.time() - t0
+    t0 = time.time()
+    pd = {k: v.to(dev) for k, v in vp.items()}
+    with torch.no_grad():
+        got = aten_oracle.decode_chunked(pd, z.to(dev), ovae, torch.float32, max_elems=1 << 24).float().cpu()
+    torch.cuda.synchronize()
+    meta["aten_gpu_fp32_seconds"] = time.time() - t0
+    meta["maxabs_aten_vs_cpu"] = float((got - ref).abs().max())
+    meta["rel_rms_aten_vs_cpu"] = fc.rel_rms(got, ref)
+    meta["ref_absmax"] = float(ref.abs().max())
+    tensors["dummy"] = torch.zeros(1)
+    finish()
 else:
     raise SystemExit(f"unknown case {CASE}")
