@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 //   * SPLIT (small grids, see conv_halo_split): blockIdx.x = tile * S + ks; the workgroup multiplies only the channel
 //     slices [ks * nsl / S, (ks + 1) * nsl / S) and stores its fp32 accumulators as a register image; conv_halo_finish_kernel
 //     adds the S images of a tile in the order ks = 0..S-1 (deterministic) and runs the shared epilogue.
-template <int PW, int BN, bool SPLIT>
+template <int PW, int BN, bool SPLIT, bool PREF = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
     constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK;
@@ -412,6 +412,60 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         }
         const char* hcur = halo0 + hb * G::HALO_BYTES;
         const int u0 = sl * 9;
+        if constexpr (PREF) {
+            // Fragment prefetch: the 18 activation fragments of column kx + 1 are requested DURING the last tap (ky = 2) of
+            // column kx, one per pair of MFMAs, each into the register its predecessor has just freed (fragment i + 2 of the
+            // current column dies with row i of that tap), so a column never starts by waiting out an LDS round trip with the
+            // MFMA pipe idle; only a slice's first column (its halo is not valid before the slice barrier) still does.
+            auto col_ptr = [&](int kx) { return hcur + (hxl + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4); };
+            bf16x8 af[MI + 2];
+            {
+                const char* sA = col_ptr(0);
+#pragma unroll
+                for (int r = 0; r < MI + 2; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky) {
+                    const int tapi = kx * 3 + ky;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < JN; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ky][jn], af[i + ky], acc[i][jn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w(ky, u0 + tapi + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bf16x8 an[MI + 2];
+                const char* sN = col_ptr(kx < 2 ? kx + 1 : 2);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int jn = 0; jn < JN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2][jn], af[i + 2], acc[i][jn], 0, 0, 0);
+                    if (kx < 2) an[i] = *(const bf16x8*)(sN + i * (HP * ROWB));
+                }
+                if (kx < 2) {
+                    an[MI] = *(const bf16x8*)(sN + MI * (HP * ROWB));
+                    an[MI + 1] = *(const bf16x8*)(sN + (MI + 1) * (HP * ROWB));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {            // keep the interleave: two MFMAs, one fragment read
+                        __builtin_amdgcn_sched_group_barrier(0x008, JN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(2, u0 + kx * 3 + 2 + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kx < 2) {
+#pragma unroll
+                    for (int r = 0; r < MI + 2; ++r) af[r] = an[r];
+                }
+            }
+        } else {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const char* sA = hcur + (hxl + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4);
@@ -433,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
                 load_w(ky, u0 + tapi + 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         hb ^= 1;
     }
@@ -522,6 +577,9 @@ int launch_halo(KArgs a, hipStream_t s) {
     if constexpr (WR) fn = (const void*)conv_halo_wr_kernel<PW, BN, false>;
     else fn = (const void*)conv_halo_kernel<PW, BN>;
     SVR2_SET_MAX_LDS(fn, G::LDS, "conv_halo");
+    // SVR2_HALO_PREF (default 1): the W-through-registers kernel with the next column's activation fragments requested
+    // under the current column's last tap; 0 = every column reads its fragments first (A/B; same bits)
+    const bool pref = WR && svr2::opt(svr2::OPT_HALO_PREF, 1) != 0;
     a.cg.patch = svr2::opt(svr2::OPT_CONV_TFAST, 0) ? 3 : 2;
     a.cg.tiles_x = (a.cg.Wo + PW - 1) / PW;
     a.cg.tiles_y = (a.cg.Ho + G::PH - 1) / G::PH;
@@ -550,7 +608,12 @@ int launch_halo(KArgs a, hipStream_t s) {
             return SVR2_OK;
         }
         a.ks_log2 = 0;
-        hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+        if (pref) {
+            SVR2_SET_MAX_LDS((const void*)(conv_halo_wr_kernel<PW, BN, false, true>), G::LDS, "conv_halo (prefetch)");
+            hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false, true>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+        } else {
+            hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
+        }
     } else {
         hipLaunchKernelGGL((conv_halo_kernel<PW, BN>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
     }

@@ -189,6 +189,12 @@ def test_conv3d_halo_resident(pkg, gpu, case, wr, lib_option):
               resid=None if res is None else dev_bf16(res, gpu))
     out = hip.conv3d(dev_bf16(x, gpu), hip.conv_weight_tiled(w5.to(gpu)), Cout, k, s, w_layout=hip.WL_TILED_128x32, **kw)
     assert_close(out, ref, f"conv3d halo {case}")
+    if wr:   # the fragment prefetch (default) only moves LDS reads: same bits as the kernel without it
+        lib_option("SVR2_CONV_SPLIT", 0)
+        a1 = hip.conv3d(dev_bf16(x, gpu), hip.conv_weight_tiled(w5.to(gpu)), Cout, k, s, w_layout=hip.WL_TILED_128x32, **kw)
+        lib_option("SVR2_HALO_PREF", 0)
+        a0 = hip.conv3d(dev_bf16(x, gpu), hip.conv_weight_tiled(w5.to(gpu)), Cout, k, s, w_layout=hip.WL_TILED_128x32, **kw)
+        assert torch.equal(a0, a1)
     if Cin % 64 == 0 and (Cout % 8 == 0 or not with_res):
         out0 = hip.conv3d(dev_bf16(x, gpu), hip.pad_weight(hip.conv_weight(w5).to(gpu)), Cout, k, s, **kw)
         assert_close(out, out0.float().cpu(), f"conv3d halo vs tap-staged {case}")

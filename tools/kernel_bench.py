@@ -214,6 +214,17 @@ if __name__ == "__main__":
                 bench_conv(4, 1080, 1920, 512, 512, tiled=True)
                 bench_conv(8, 1080, 1920, 256, 256, tiled=True)
         hip.set_option("SVR2_CONV_TFAST", None)
+    if "halopref" in which:   # same-process A/B of the fragment prefetch (SVR2_HALO_PREF)
+        for rnd in range(3):
+            for v in (0, 1):
+                hip.set_option("SVR2_HALO_PREF", v)
+                print(f"-- round {rnd} SVR2_HALO_PREF={v}", flush=True)
+                bench_conv(4, 2160, 3840, 128, 128, tiled=True)
+                bench_conv(4, 2160, 3840, 256, 128, tiled=True)
+                bench_conv(4, 1080, 1920, 256, 256, tiled=True)
+                bench_conv(4, 1080, 1920, 512, 512, tiled=True)
+                bench_conv(5, 272, 480, 512, 512, tiled=True)
+        hip.set_option("SVR2_HALO_PREF", None)
     if "halopmc" in which:   # few launches of the three dominant halo-conv shapes for counter collection
         bench_conv(4, 2160, 3840, 128, 128, tiled=True)
         bench_conv(4, 1080, 1920, 256, 256, tiled=True)
