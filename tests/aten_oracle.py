@@ -1,4 +1,4 @@
-"""The oracle's VAE decoder (oracle/seedvr2_ref/vae.py, unchanged code) EXECUTED BY ATen ON THE GPU in fp32 - for the one
+"""The oracle's VAE decoder (oracle/seedvr2_ref/vae.py, unchanged code) EXECUTED BY ATen ON THE GPU - for the one
 at-size case the CPU cannot finish inside a 20-minute GPU-box call (5 frames of 4K through the decoder: ~1400 s on 64 host
 threads).  Test infrastructure only.
 
@@ -78,8 +78,10 @@ def decode_chunked(p, latent, ovae, dtype=torch.float32, max_elems: int = 1 << 3
     return torch.cat(outs, dim=1).permute(1, 2, 3, 0).contiguous()
 
 
-def decode_fp32_on_device(p, latent, ovae, dev):
+def decode_on_device(p, latent, ovae, dev, dtype=torch.float32):
+    """dtype fp32: the exact-arithmetic flavour (slow at 4K: MIOpen's fp32 3-D convolutions did not finish five 4K frames
+    in 15 minutes); dtype bf16: every op in bf16 like the reference's own GPU / CPU paths (its PyTorch ops are ATen's)."""
     pd = {k: v.to(dev) for k, v in p.items() if k.startswith("decoder.")}
     with torch.no_grad():
-        out = decode_chunked(pd, latent.to(dev), ovae, torch.float32)
+        out = decode_chunked(pd, latent.to(dev), ovae, dtype)
     return out.float().cpu()

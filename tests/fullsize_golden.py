@@ -222,12 +222,14 @@ elif CASE == "vae4k_dec":
     meta["hip_seconds_first_call"] = time.time() - t0
     del vae
     torch.cuda.empty_cache()
-    if MODE == "aten":
+    if MODE in ("aten", "aten_bf16"):
         import aten_oracle
+        dt = torch.bfloat16 if MODE == "aten_bf16" else torch.float32
         t0 = time.time()
-        ref = aten_oracle.decode_fp32_on_device(vp, z, ovae, dev)          # [5,2160,3840,3] fp32 CPU
-        meta["oracle_aten_fp32_seconds"] = time.time() - t0
-        meta["oracle_flavour"] = "oracle code executed by ATen on the GPU in fp32 (strip-mined convs); see tests/aten_oracle.py"
+        ref = aten_oracle.decode_on_device(vp, z, ovae, dev, dt)          # [5,2160,3840,3] fp32 CPU
+        meta["oracle_aten_seconds"] = time.time() - t0
+        meta["oracle_flavour"] = (f"the oracle's code executed by ATen on the GPU in {'bf16 (op by op, like the reference)' if dt == torch.bfloat16 else 'fp32'}"
+                                  " (piecewise library calls, one latent frame per temporal chunk); see tests/aten_oracle.py")
     else:
         t0 = time.time()
         ref = ovae.decode(vp, z, ovae.VAEConfig(), torch.bfloat16).to(torch.bfloat16).float().permute(1, 2, 3, 0).contiguous()
@@ -258,6 +260,19 @@ elif CASE == "aten_check":
     meta["maxabs_aten_vs_cpu"] = float((got - ref).abs().max())
     meta["rel_rms_aten_vs_cpu"] = fc.rel_rms(got, ref)
     meta["ref_absmax"] = float(ref.abs().max())
+    # bf16 flavour: ATen bf16 on the GPU against the CPU bf16 oracle (two op-by-op bf16 evaluations: bf16 noise apart) and
+    # both against the fp32 truth
+    t0 = time.time()
+    with torch.no_grad():
+        ref16 = ovae.decode({k: v for k, v in vp.items()}, z, ovae.VAEConfig(), torch.bfloat16).float().permute(1, 2, 3, 0).contiguous()
+    meta["cpu_bf16_seconds"] = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        got16 = aten_oracle.decode_chunked(pd, z.to(dev), ovae, torch.bfloat16, max_elems=1 << 24).float().cpu()
+    torch.cuda.synchronize()
+    meta["aten_gpu_bf16_seconds"] = time.time() - t0
+    meta["psnr_pm1"] = {"aten_bf16_vs_cpu_bf16": fc.psnr(got16, ref16, 2.0), "aten_bf16_vs_fp32": fc.psnr(got16, ref, 2.0),
+                        "cpu_bf16_vs_fp32": fc.psnr(ref16, ref, 2.0)}
     tensors["dummy"] = torch.zeros(1)
     finish()
 else:
