@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 //   * SPLIT (small grids, see conv_halo_split): blockIdx.x = tile * S + ks; the workgroup multiplies only the channel
 //     slices [ks * nsl / S, (ks + 1) * nsl / S) and stores its fp32 accumulators as a register image; conv_halo_finish_kernel
 //     adds the S images of a tile in the order ks = 0..S-1 (deterministic) and runs the shared epilogue.
-template <int PW, int BN, bool SPLIT, int PREF = 0>
+template <int PW, int BN, bool SPLIT, bool PREF = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
     constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK;
@@ -402,78 +402,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     load_w(1, sl0 * 9 + 1);
     load_w(2, sl0 * 9 + 2);
 
-    if constexpr (PREF == 2) {
-        // Cross-slice fragment prefetch: three halo buffers and the slice barrier moved in front of a slice's LAST tap.  At
-        // that barrier the next slice's halo has landed for every wave (vmcnt retires in order: its pieces are older than the
-        // six W loads a wave keeps in flight), so the last tap can already request the next slice's first column, and the
-        // slice after that streams into the buffer nobody has read since the previous slice.  No column of the K loop
-        // starts with an exposed LDS round trip any more except the tile's very first.
-        static_assert(3 * G::HALO_BYTES <= G::LDS, "three halo buffers");
-        auto col_of = [&](const char* hbuf, int kx) { return hbuf + (hxl + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4); };
-        if (hrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (hrole && sl0 + 1 < sl1) {
-            if (++cs == ncs) { cs = 0; ++tap_t; }
-            issue_halo(slice_base(tap_t, cs), halo0 + G::HALO_BYTES);
-        }
-        bf16x8 af[MI + 2];
-        {
-            const char* sA = col_of(halo0, 0);
-#pragma unroll
-            for (int r = 0; r < MI + 2; ++r) af[r] = *(const bf16x8*)(sA + r * (HP * ROWB));
-        }
-        for (int sl = sl0; sl < sl1; ++sl) {
-            const char* hcur = halo0 + hb * G::HALO_BYTES;
-            const int nb = hb == 2 ? 0 : hb + 1, nnb = nb == 2 ? 0 : nb + 1;
-            const char* hnext = halo0 + nb * G::HALO_BYTES;
-            const int u0 = sl * 9;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-                for (int ky = 0; ky < 2; ++ky) {
-                    const int tapi = kx * 3 + ky;
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < JN; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ky][jn], af[i + ky], acc[i][jn], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_w(ky, u0 + tapi + 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (kx == 2) {
-                    // every wave executes this (also on the last slice, where it guards nothing): no branch around the barrier
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    asm volatile("s_barrier" ::: "memory");
-                    if (hrole && sl + 2 < sl1) {
-                        if (++cs == ncs) { cs = 0; ++tap_t; }
-                        issue_halo(slice_base(tap_t, cs), halo0 + nnb * G::HALO_BYTES);
-                    }
-                }
-                // fragment i of the next column goes straight into slot i: slots 0 .. i + 1 are dead by row i of this tap
-                const char* sN = kx < 2 ? col_of(hcur, kx + 1) : col_of(hnext, 0);   // last slice: a harmless read of stale LDS
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                    for (int jn = 0; jn < JN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2][jn], af[i + 2], acc[i][jn], 0, 0, 0);
-                    af[i] = *(const bf16x8*)(sN + i * (HP * ROWB));
-                }
-                af[MI] = *(const bf16x8*)(sN + MI * (HP * ROWB));
-                af[MI + 1] = *(const bf16x8*)(sN + (MI + 1) * (HP * ROWB));
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {            // keep the interleave: two MFMAs, one fragment read
-                    __builtin_amdgcn_sched_group_barrier(0x008, JN, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_w(2, u0 + kx * 3 + 2 + 3);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            hb = nb;
-        }
-    } else
     for (int sl = sl0; sl < sl1; ++sl) {
         // the halo of this slice has landed for every wave and every wave is done reading the other buffer
         if (hrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,11 +412,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         }
         const char* hcur = halo0 + hb * G::HALO_BYTES;
         const int u0 = sl * 9;
-        if constexpr (PREF == 1) {
+        if constexpr (PREF) {
             // Fragment prefetch: the 18 activation fragments of column kx + 1 are requested DURING the last tap (ky = 2) of
             // column kx, one per pair of MFMAs, each into the register its predecessor has just freed (fragment i + 2 of the
             // current column dies with row i of that tap), so a column never starts by waiting out an LDS round trip with the
             // MFMA pipe idle; only a slice's first column (its halo is not valid before the slice barrier) still does.
+            // Measured +0.8 .. 2 % (profiles/r03_conv/halopref_ab.log), bit-identical.  The cross-slice form (three halo
+            // buffers, slice barrier in front of a slice's last tap so that this tap can request the next slice's first
+            // column) was written too: the DMA issue then sits where all 18 fragments are live and spills 11-12 registers
+            // into the loop; not kept (commit "conv_halo_wr fragment prefetch measured").
             auto col_ptr = [&](int kx) { return hcur + (hxl + kx) * ROWB + ((fq ^ (((hxl + kx) >> 2) & 3)) << 4); };
             bf16x8 af[MI + 2];
             {

@@ -112,9 +112,10 @@ def bench_attn_ab(grid, H=20, versions=(1, 2, 3), rounds=3):
 def bench_attn512(frames, P):
     qkv = rb(frames * P, 1536)
     out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
-    # same-process A/B, interleaved: SVR2_ATTN5_V 0 = plain loops, 1 = software-pipelined fragment groups (default)
+    # same-process A/B, interleaved: SVR2_ATTN5_V 0 = lockstep, plain loops; 1 = lockstep, software-pipelined fragment
+    # groups; 2 = skewed (waves 4-7 one PV phase late, default)
     for rnd in range(3):
-        for var in (0, 1):
+        for var in (0, 1, 2):
             hip.set_option("SVR2_ATTN5_V", var)
             t = timeit(lambda: hip.attn_d512(qkv, frames, P, out), iters=3, warm=1)
             print(f"attn_d512[SVR2_ATTN5_V={var}] frames={frames} P={P}: {t*1e3:.3f} ms  {4*512*P*P*frames/t/1e12:.1f} TFLOP/s", flush=True)
