@@ -114,8 +114,9 @@ def bench_attn512(frames, P):
     out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
     # same-process A/B, interleaved: SVR2_ATTN5_V 0 = lockstep, plain loops; 1 = lockstep, software-pipelined fragment
     # groups; 2 = skewed (waves 4-7 one PV phase late, default)
-    for rnd in range(3):
-        for var in (0, 1, 2):
+    variants = tuple(int(v) for v in os.environ.get("SVR2_KB_ATTN5_VARS", "0,1,2").split(","))   # "2": counters on the default only
+    for rnd in range(3 if len(variants) > 1 else 1):
+        for var in variants:
             hip.set_option("SVR2_ATTN5_V", var)
             t = timeit(lambda: hip.attn_d512(qkv, frames, P, out), iters=3, warm=1)
             print(f"attn_d512[SVR2_ATTN5_V={var}] frames={frames} P={P}: {t*1e3:.3f} ms  {4*512*P*P*frames/t/1e12:.1f} TFLOP/s", flush=True)
