@@ -338,205 +338,6 @@ __global__ __launch_bounds__(NTH5) void attn_d512_kernel(const Attn5Args a) {
     }
 }
 
-// ---- skewed form of attn_d512_kernel (default).  Same arithmetic per wave, same order, same bits; what changes is WHEN the
-// two waves of a SIMD do it.  In the lockstep kernel above all eight waves leave the tile barrier together, issue their DMA
-// pieces together (8 pieces of ~60-100 issue cycles each with no MFMA behind them), run QK^T together, do their softmax VALU
-// work together (MFMA pipe idle) and run PV together.  Here waves 4-7 (the SIMD partners of waves 0-3) run one PV phase
-// late:        waves 0-3:  barrier | DMA issue | QK^T(t) | softmax(t) | PV(t)
-//              waves 4-7:  barrier | PV(t-1)   | DMA issue | QK^T(t) | softmax(t)
-// so a SIMD's DMA issue and softmax phases sit under its partner's MFMAs.  V(t-1) must outlive tile t, hence three V stages
-// (K keeps two): 5 x 32 KiB = the whole LDS.  Barrier t guarantees that tile t has landed and that V(t-2) / K(t-1), the
-// stages DMA(t+1) overwrites, have been read by everyone.
-constexpr int ATT5S_LDS = 5 * KV5_BYTES;          // K[2] + V[3] = 160 KiB
-
-__global__ __launch_bounds__(NTH5) void attn_d512_skew_kernel(const Attn5Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, kq = lane >> 4;
-    const long long s0 = (long long)blockIdx.y * a.P;
-    const int q0 = blockIdx.x * QB5;
-    const int len = a.P;
-    char* const kst = smem;
-    char* const vst = smem + 2 * KV5_BYTES;
-
-    bf16x8 qf[16];
-    {
-        int qr = q0 + wave * 16 + l15;
-        if (qr > len - 1) qr = len - 1;
-        const bf16* qp = a.q + (s0 + qr) * a.ld + kq * 8;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
-    }
-    auto issue = [&](int t, int vs) {                 // tile t -> K stage t & 1, V stage vs = t % 3
-        char* sK = kst + (t & 1) * KV5_BYTES;
-        char* sV = vst + vs * KV5_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = wave * 4 + i;
-            int kr = t * KB5 + key;
-            if (kr > len - 1) kr = len - 1;
-            const long long row = (s0 + kr) * a.ld;
-            int l = lane;
-            asm volatile("" : "+v"(l));               // per piece, not hoisted (see attn_d512_kernel)
-            glds16(a.k + row + ((l ^ (key & 15)) << 3), sK + key * 1024);
-            glds16(a.v + row + ((l ^ ((key & 7) << 1)) << 3), sV + key * 1024);
-        }
-    };
-
-    f32x4 oacc[32];
-#pragma unroll
-    for (int dt = 0; dt < 32; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const int tq = l15 >> 2, tp = l15 & 3;
-    const int koff0 = l15 * 1024 + (((((l15 >> 2) & 3) << 2) | (kq ^ (l15 & 3))) << 4);
-    const int voff0 = (4 * kq + tq) * 1024 + (((((4 * kq + tq) & 7) << 1) | (tp >> 1)) << 4) + (tp & 1) * 8;
-    const float c = a.scale_log2;
-    const int nt = (len + KB5 - 1) / KB5;
-
-    // S^T = K . Q^T of one tile, fragment groups one ahead (attn_d512_kernel<1>)
-    auto qk = [&](const char* sK, f32x4 (&sacc)[2]) {
-        int kb = koff0;
-        asm volatile("" : "+v"(kb));
-        bf16x8 fa[4], fb[4];
-        auto load_k = [&](int g, bf16x8* f) {
-            const char* kp = sK + (g >> 2) * 16 * 1024 + (g & 3) * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(kp + (kb ^ (j << 6)));
-        };
-        load_k(0, fa);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            bf16x8* cur = (g & 1) ? fb : fa;
-            bf16x8* nxt = (g & 1) ? fa : fb;
-            if (g + 1 < 8) load_k(g + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            if ((g & 3) == 0) sacc[g >> 2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                sacc[g >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], qf[(g & 3) * 4 + j], sacc[g >> 2], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // online softmax of one tile: running max / sum, deferred rescale of O^T, P^T as bf16 (lane = query l15, keys 16 k2 + 4 kq + r)
-    auto softmax = [&](int t, f32x4 (&sacc)[2]) -> bf16x8 {
-        if (t == nt - 1 && (len % KB5) != 0) {
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (t * KB5 + k2 * 16 + 4 * kq + r >= len) sacc[k2][r] = -INFINITY;
-        }
-        float mx = sacc[0][0];
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[k2][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > 4.0f) != 0) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 32; ++dt) oacc[dt] *= alpha;
-        }
-        const float mc = m_run * c;
-        float psum = 0.f;
-        bf16x8 pf;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[k2][r], c, -mc));
-                psum += p;
-                pf[k2 * 4 + r] = f2bf(p);
-            }
-        l_run += psum;
-        return pf;
-    };
-    // O^T += V^T . P^T of one tile, fragment groups one ahead
-    auto pv = [&](const char* sV, const bf16x8 pf) {
-        int vb = voff0;
-        asm volatile("" : "+v"(vb));
-        bf16x8 fa[4], fb[4];
-        auto load_v = [&](int g, bf16x8* f) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int dt = g * 4 + j;
-                const char* p0 = sV + (vb ^ ((dt & 7) << 5)) + (dt >> 3) * 256;
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0));
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)LDS_PTR(p0 + 16 * 1024));
-                f[j] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        };
-        load_v(0, fa);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            bf16x8* cur = (g & 1) ? fb : fa;
-            bf16x8* nxt = (g & 1) ? fa : fb;
-            if (g + 1 < 8) load_v(g + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                oacc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], pf, oacc[g * 4 + j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    issue(0, 0);
-    if (wave < 4) {
-        int vs = 0;                                    // V stage of tile t
-        for (int t = 0; t < nt; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int vn = vs == 2 ? 0 : vs + 1;
-            if (t + 1 < nt) issue(t + 1, vn);
-            f32x4 sacc[2];
-            qk(kst + (t & 1) * KV5_BYTES, sacc);
-            const bf16x8 pf = softmax(t, sacc);
-            pv(vst + vs * KV5_BYTES, pf);
-            vs = vn;
-        }
-    } else {
-        int vs = 0;
-        bf16x8 pf;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = f2bf(0.f);
-        for (int t = 0; t < nt; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int vn = vs == 2 ? 0 : vs + 1;
-            // P^T of the previous tile times its V: that stage is not overwritten before DMA(t + 2).  (t = 0: P = 0 against
-            // whatever stage 2 holds would be harmless for finite data only, hence the branch.)
-            if (t > 0) pv(vst + (vs == 0 ? 2 : vs - 1) * KV5_BYTES, pf);
-            if (t + 1 < nt) issue(t + 1, vn);
-            f32x4 sacc[2];
-            qk(kst + (t & 1) * KV5_BYTES, sacc);
-            pf = softmax(t, sacc);
-            vs = vn;
-        }
-        pv(vst + (vs == 0 ? 2 : vs - 1) * KV5_BYTES, pf);
-    }
-
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qr = q0 + wave * 16 + l15;
-    if (qr < len) {
-        bf16* op = a.out + (s0 + qr) * a.ldo + 4 * kq;
-#pragma unroll
-        for (int dt = 0; dt < 32; ++dt) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[dt][e] * inv);
-            *(bf16x4*)(op + dt * 16) = o;
-        }
-    }
-}
-
 inline int gn_blocks(long long P, int C) {
     const int ppb = 256 / (C >> 3);
     long long nb = (P + (long long)ppb * 8 - 1) / ((long long)ppb * 8);
@@ -611,23 +412,22 @@ extern "C" int svr2_attn_d512(const void* q, const void* k, const void* v, int64
                SVR2_E_SHAPE, "svr2_attn_d512: bad sizes");
     SVR2_CHECK(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), SVR2_E_ALIGN,
                "svr2_attn_d512: pointers must be 16-byte aligned");
-    // SVR2_ATTN5_V: 2 (default) = the skewed kernel (waves 4-7 one PV phase late); 1 = all waves in lockstep with the
-    // software-pipelined fragment schedule; 0 = lockstep, plain loops.  All three give the same bits.
+    // SVR2_ATTN5_V: 1 (default) = the software-pipelined fragment schedule; 0 = the plain loops (A/B; same bits).
     // A third form - pairs of waves that split the head dimension (32 queries per pair on 32x32x16 MFMAs, S^T halves
     // exchanged through LDS: 40 instead of 64 KiB of LDS reads per wave and tile) - was built, parity-green and SLOWER
     // (923 vs 1 063 TFLOP/s at 129 600 tokens, profiles/r03_attn512): the kernel is bound by the K/V delivery into LDS
     // plus reads plus MFMAs in series, not by the LDS reads alone, and the exchange barrier and the duplicated softmax
-    // cost more than the reads they save.  Removed; the code is in the history (the commit before this comment).
-    const int ver = svr2::opt(svr2::OPT_ATTN5_V, 2);
-    if (ver == 2) SVR2_SET_MAX_LDS(attn_d512_skew_kernel, ATT5S_LDS, "svr2_attn_d512");
-    else if (ver == 1) SVR2_SET_MAX_LDS(attn_d512_kernel<1>, ATT5_LDS, "svr2_attn_d512");
+    // cost more than the reads they save.  Removed; the code is in the history (commit 8fe3fb8).
+    // A fourth - waves 4-7 one PV phase behind waves 0-3 (three V stages = all of the LDS), so that a SIMD's DMA issue and
+    // softmax phases sit under its partner's MFMAs - was built too, bit-identical, and 2 % SLOWER (1 035 vs 1 054-1 061
+    // TFLOP/s): the phases were not what the pipe waits for either.  Removed as well (history: the commit before this one).
+    const int ver = svr2::opt(svr2::OPT_ATTN5_V, 1);
+    if (ver == 1) SVR2_SET_MAX_LDS(attn_d512_kernel<1>, ATT5_LDS, "svr2_attn_d512");
     else SVR2_SET_MAX_LDS(attn_d512_kernel<0>, ATT5_LDS, "svr2_attn_d512");
     Attn5Args a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
     a.ld = ld; a.ldo = ldo; a.P = P; a.scale_log2 = scale * 1.4426950408889634f;
-    if (ver == 2)
-        hipLaunchKernelGGL(attn_d512_skew_kernel, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5S_LDS, (hipStream_t)stream, a);
-    else if (ver == 1)
+    if (ver == 1)
         hipLaunchKernelGGL(attn_d512_kernel<1>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(attn_d512_kernel<0>, dim3((P + QB5 - 1) / QB5, frames), dim3(NTH5), ATT5_LDS, (hipStream_t)stream, a);

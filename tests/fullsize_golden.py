@@ -7,7 +7,7 @@ the stored crops in seconds: tests/test_gpu_fullsize_golden.py).
                                                         (stage by stage with per-stage CPU seconds: the measured CPU baseline)
     python tests/fullsize_golden.py dit4k               3-layer full-width NaDiT on grid (6,135,240) vs bf16 + fp32 oracle
     python tests/fullsize_golden.py vae4k_enc           5-frame 4K clip through the VAE encoder (chunks 1 + 4, carries) vs bf16 oracle
-    python tests/fullsize_golden.py vae4k_dec [aten]    2 latent frames -> 5 frames at 4K through the decoder (carries)
+    python tests/fullsize_golden.py vae4k_dec           2 latent frames -> 5 frames of 2160 x 1920 through the decoder (carries)
 
 Outputs go to gpurun_out/golden/<case>.safetensors + .json; they are copied into tests/golden/fullsize/ and committed.
 """
@@ -215,65 +215,19 @@ elif CASE == "vae4k_dec":
     vp = {k: v.detach().cpu() for k, v in vsd.items()}
     del vsd
     z = fc.vae4k_decode_latent()
-    meta["input"] = "seeded latent [2,270,480,16] -> VAE decode (one latent frame per chunk, causal carries) -> [5,2160,3840,3]"
+    meta["input"] = (f"seeded latent {list(z.shape)} -> VAE decode (HIP: one latent frame per chunk, causal carries) -> "
+                     f"[5,2160,{fc.VAE4K_DEC_W},3]: full 4K height, half width")
     t0 = time.time()
     got = vae.decode(z.to(dev)).float().cpu()
     torch.cuda.synchronize()
     meta["hip_seconds_first_call"] = time.time() - t0
-    del vae
-    torch.cuda.empty_cache()
-    if MODE in ("aten", "aten_bf16"):
-        import aten_oracle
-        dt = torch.bfloat16 if MODE == "aten_bf16" else torch.float32
-        t0 = time.time()
-        ref = aten_oracle.decode_on_device(vp, z, ovae, dev, dt)          # [5,2160,3840,3] fp32 CPU
-        meta["oracle_aten_seconds"] = time.time() - t0
-        meta["oracle_flavour"] = (f"the oracle's code executed by ATen on the GPU in {'bf16 (op by op, like the reference)' if dt == torch.bfloat16 else 'fp32'}"
-                                  " (piecewise library calls, one latent frame per temporal chunk); see tests/aten_oracle.py")
-    else:
-        t0 = time.time()
-        ref = ovae.decode(vp, z, ovae.VAEConfig(), torch.bfloat16).to(torch.bfloat16).float().permute(1, 2, 3, 0).contiguous()
-        meta["oracle_bf16_seconds"] = time.time() - t0
-        meta["oracle_flavour"] = "bf16 CPU oracle"
+    t0 = time.time()
+    ref = ovae.decode(vp, z, ovae.VAEConfig(), torch.bfloat16).to(torch.bfloat16).float().permute(1, 2, 3, 0).contiguous()
+    meta["oracle_bf16_seconds"] = time.time() - t0
+    meta["oracle_flavour"] = "bf16 CPU oracle"
     put_crops("dec", ref, 64)
     compare("dec", got, "dec", 64, peak=2.0)
     meta["psnr_full_hip_vs_oracle_pm1"] = fc.psnr(got, ref, peak=2.0)
-    finish()
-elif CASE == "aten_check":
-    # the piecewise ATen-on-GPU executor of the oracle's decoder against the plain CPU oracle (fp32) at a size the CPU
-    # finishes in minutes: 2 latent frames of 68 x 120 -> 5 frames of 544 x 960, pieces capped at 2^24 elements so that every
-    # full-resolution conv is cut into strips like the 4K run cuts them
-    import aten_oracle
-    vp = {k: v.to(torch.bfloat16).float() for k, v in ovae.synthetic_params(ovae.VAEConfig(), 1).items() if k.startswith("decoder.")}
-    g = torch.Generator().manual_seed(12)
-    z = torch.randn(2, 68, 120, 16, generator=g).to(torch.bfloat16)
-    t0 = time.time()
-    with torch.no_grad():
-        ref = ovae.decode(vp, z, ovae.VAEConfig(), torch.float32).permute(1, 2, 3, 0).contiguous()
-    meta["cpu_fp32_seconds"] = time.time() - t0
-    t0 = time.time()
-    pd = {k: v.to(dev) for k, v in vp.items()}
-    with torch.no_grad():
-        got = aten_oracle.decode_chunked(pd, z.to(dev), ovae, torch.float32, max_elems=1 << 24).float().cpu()
-    torch.cuda.synchronize()
-    meta["aten_gpu_fp32_seconds"] = time.time() - t0
-    meta["maxabs_aten_vs_cpu"] = float((got - ref).abs().max())
-    meta["rel_rms_aten_vs_cpu"] = fc.rel_rms(got, ref)
-    meta["ref_absmax"] = float(ref.abs().max())
-    # bf16 flavour: ATen bf16 on the GPU against the CPU bf16 oracle (two op-by-op bf16 evaluations: bf16 noise apart) and
-    # both against the fp32 truth
-    t0 = time.time()
-    with torch.no_grad():
-        ref16 = ovae.decode({k: v for k, v in vp.items()}, z, ovae.VAEConfig(), torch.bfloat16).float().permute(1, 2, 3, 0).contiguous()
-    meta["cpu_bf16_seconds"] = time.time() - t0
-    t0 = time.time()
-    with torch.no_grad():
-        got16 = aten_oracle.decode_chunked(pd, z.to(dev), ovae, torch.bfloat16, max_elems=1 << 24).float().cpu()
-    torch.cuda.synchronize()
-    meta["aten_gpu_bf16_seconds"] = time.time() - t0
-    meta["psnr_pm1"] = {"aten_bf16_vs_cpu_bf16": fc.psnr(got16, ref16, 2.0), "aten_bf16_vs_fp32": fc.psnr(got16, ref, 2.0),
-                        "cpu_bf16_vs_fp32": fc.psnr(ref16, ref, 2.0)}
-    tensors["dummy"] = torch.zeros(1)
     finish()
 else:
     raise SystemExit(f"unknown case {CASE}")

@@ -112,9 +112,8 @@ def bench_attn_ab(grid, H=20, versions=(1, 2, 3), rounds=3):
 def bench_attn512(frames, P):
     qkv = rb(frames * P, 1536)
     out = torch.empty(frames * P, 512, dtype=torch.bfloat16, device=dev)
-    # same-process A/B, interleaved: SVR2_ATTN5_V 0 = lockstep, plain loops; 1 = lockstep, software-pipelined fragment
-    # groups; 2 = skewed (waves 4-7 one PV phase late, default)
-    variants = tuple(int(v) for v in os.environ.get("SVR2_KB_ATTN5_VARS", "0,1,2").split(","))   # "2": counters on the default only
+    # same-process A/B, interleaved: SVR2_ATTN5_V 0 = plain loops; 1 = software-pipelined fragment groups (default)
+    variants = tuple(int(v) for v in os.environ.get("SVR2_KB_ATTN5_VARS", "0,1").split(","))   # "1": counters on the default only
     for rnd in range(3 if len(variants) > 1 else 1):
         for var in variants:
             hip.set_option("SVR2_ATTN5_V", var)
