@@ -7,7 +7,7 @@ the stored crops in seconds: tests/test_gpu_fullsize_golden.py).
                                                         (stage by stage with per-stage CPU seconds: the measured CPU baseline)
     python tests/fullsize_golden.py dit4k               3-layer full-width NaDiT on grid (6,135,240) vs bf16 + fp32 oracle
     python tests/fullsize_golden.py vae4k_enc           5-frame 4K clip through the VAE encoder (chunks 1 + 4, carries) vs bf16 oracle
-    python tests/fullsize_golden.py vae4k_dec           2 latent frames -> 5 frames of 2160 x 1920 through the decoder (carries)
+    python tests/fullsize_golden.py vae4k_dec           2 latent frames -> 5 frames of 4K through the decoder (carries)
 
 Outputs go to gpurun_out/golden/<case>.safetensors + .json; they are copied into tests/golden/fullsize/ and committed.
 """
@@ -216,7 +216,7 @@ elif CASE == "vae4k_dec":
     del vsd
     z = fc.vae4k_decode_latent()
     meta["input"] = (f"seeded latent {list(z.shape)} -> VAE decode (HIP: one latent frame per chunk, causal carries) -> "
-                     f"[5,2160,{fc.VAE4K_DEC_W},3]: full 4K height, half width")
+                     f"[5,2160,{fc.VAE4K_DEC_W},3]")
     t0 = time.time()
     got = vae.decode(z.to(dev)).float().cpu()
     torch.cuda.synchronize()

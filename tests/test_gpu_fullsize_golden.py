@@ -7,8 +7,8 @@ tests/golden/fullsize/ as data: crops, per-frame means, what the HIP path measur
   4k7b   the same with NaDiT-7B (cfg4's model at cfg4's shapes)
   dit4k  3-layer full-width NaDiT (separate / shared / vid-only last; regular, shifted, regular windows) on cfg3's grid
          (6,135,240): the only grid with two temporal windows (810-token windows) [ref: dit_3b/window.py:28-83]
-  vae4k_enc / vae4k_dec   5 frames through the VAE encoder at 4K (chunks 1 + 4) / decoder at 2160 x 1920 (one latent frame
-         per chunk): causal carries across temporal chunks at size [ref: causal_inflation_lib.py:250-305]
+  vae4k_enc / vae4k_dec   5 frames of 4K through the VAE encoder (chunks 1 + 4) / decoder (one latent frame per chunk):
+         causal carries across temporal chunks at 4K [ref: causal_inflation_lib.py:250-305]
 
 Tolerance (floating point, stated here): on the crops, PSNR(hip, oracle) >= recorded - 0.3 dB, max-abs <= 1.25 x recorded,
 relative rms error of latents <= 1.1 x recorded; per-frame channel means of the WHOLE output within 1.5 x recorded + 1e-4.
