@@ -182,3 +182,23 @@ def test_oracle_noise_injection_semantics():
     aug = b1 * 0.1 + b2 * 0.05
     want = ((1 - t / 1000.0) * lat.float() + (t / 1000.0) * aug.float()).to(torch.bfloat16)
     assert out.dtype == torch.bfloat16 and torch.equal(out, want)
+
+
+def test_piecewise_executor_of_the_oracle_decoder_matches_the_plain_oracle():
+    """tests/piecewise_oracle.py runs the oracle's decoder one latent frame per chunk with library calls on pieces (one output
+    frame x a strip of rows per conv3d call, one frame per group_norm call): same result as the plain oracle to fp32 rounding
+    (limits small enough to cut every conv); in bf16 the two are bf16 noise apart."""
+    import piecewise_oracle
+    from seedvr2_ref import vae as ovae
+    cfg = ovae.VAEConfig()
+    p = ovae.synthetic_params(cfg, 0)
+    z = torch.randn(2, 4, 6, 16, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ref = ovae.decode(p, z, cfg, torch.float32).permute(1, 2, 3, 0)
+        got = piecewise_oracle.decode_chunked(p, z, ovae, torch.float32, max_elems=20000)
+        ref16 = ovae.decode(p, z, cfg, torch.bfloat16).float().permute(1, 2, 3, 0)
+        got16 = piecewise_oracle.decode_chunked(p, z, ovae, torch.bfloat16, max_elems=20000).float()
+    assert got.shape == ref.shape == (5, 32, 48, 3)
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert (got16 - ref16).pow(2).mean().sqrt() <= 1.5 * (ref16 - ref).pow(2).mean().sqrt()
+    assert ovae.F is torch.nn.functional        # the executor restores the module
