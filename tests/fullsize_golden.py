@@ -200,7 +200,11 @@ elif CASE == "vae4k_enc":
     meta["hip_seconds_first_call"] = time.time() - t0
     t0 = time.time()
     x = opipe.transform(lr.to(torch.bfloat16).permute(0, 3, 1, 2), res)
-    ref = ovae.encode(vp, x, ovae.VAEConfig(), torch.bfloat16).to(torch.bfloat16).float()
+    import piecewise_oracle
+    vpe = {k: v for k, v in vp.items() if k.startswith("encoder.")}
+    with torch.no_grad():   # library calls on pieces below 2^31 elements (see tests/piecewise_oracle.py)
+        ref = piecewise_oracle.encode_piecewise(vpe, x, ovae, torch.bfloat16, max_elems=1 << 31).to(torch.bfloat16).float()
+    meta["oracle_flavour"] = "bf16 CPU oracle, library calls on pieces (tests/piecewise_oracle.py)"
     meta["oracle_bf16_seconds"] = time.time() - t0
     put_crops("latent", ref, 32)
     compare("latent", lat, "latent", 32)

@@ -75,3 +75,12 @@ def decode_chunked(p, latent, ovae, dtype=torch.float32, max_elems: int = 1 << 3
             outs.append(ovae.decoder(pp, z[:, t:t + 1], cfg, st))
             st.active = True
     return torch.cat(outs, dim=1).permute(1, 2, 3, 0).contiguous()
+
+
+def encode_piecewise(p, x, ovae, dtype=torch.float32, max_elems: int = 1 << 30):
+    """ovae.encode (unsliced) with piecewise library calls.  x [3,T,H,W] in [-1,1] -> latent [T_l,h,w,16]."""
+    cfg = ovae.CFG
+    pp = {k: v.to(dtype) for k, v in p.items()}
+    with piecewise(ovae, max_elems):
+        m = ovae.encoder(pp, x.to(dtype), cfg)[: cfg.latent_channels]
+    return (m * cfg.scaling_factor).permute(1, 2, 3, 0).contiguous()

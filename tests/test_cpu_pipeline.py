@@ -202,3 +202,9 @@ def test_piecewise_executor_of_the_oracle_decoder_matches_the_plain_oracle():
     assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
     assert (got16 - ref16).pow(2).mean().sqrt() <= 1.5 * (ref16 - ref).pow(2).mean().sqrt()
     assert ovae.F is torch.nn.functional        # the executor restores the module
+    x = torch.rand(3, 5, 32, 48, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    with torch.no_grad():
+        e_ref = ovae.encode(p, x, cfg, torch.float32)
+        e_got = piecewise_oracle.encode_piecewise(p, x, ovae, torch.float32, max_elems=20000)
+    assert e_got.shape == e_ref.shape == (2, 4, 6, 16)
+    assert (e_got - e_ref).abs().max() <= 2e-5 * e_ref.abs().max()

@@ -32,8 +32,12 @@ def meta():
         return json.load(fh)
 
 
-def test_vae_vs_reference_module_outputs(pkg, gpu, meta):
+@pytest.mark.parametrize("split", [1, 0])
+def test_vae_vs_reference_module_outputs(pkg, gpu, meta, split, lib_option):
+    """split = 1 (default): the tile-starved convs of these small grids take the split-K path with GroupNorm partial sums
+    (conv_halo_wr<.., SPLIT> + reduce + finish); split = 0: the unsplit kernel.  Both against the reference module's outputs."""
     from seedvr2_ref import vae as ovae
+    lib_option("SVR2_CONV_SPLIT", split)
     gold = load_file(os.path.join(GOLD, "vae_model_pins.safetensors"))
     m = meta["G16h"]
     ch = tuple(m["block_out_channels"])
