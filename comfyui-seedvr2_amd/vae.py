@@ -143,8 +143,12 @@ class VideoVAEHip:
             if name in st.next_carry:          # the norm that produced x already stored them (_norm carry_for=)
                 st.mem[name] = st.next_carry.pop(name)
             elif x.shape[0] >= keep:
+                # a VIEW of the chunk's last frames, not a copy: x is the output of a kernel that nothing writes again (a
+                # resnet's conv2, the pixel-shuffle GEMM, the input chunk), the slice of the leading dimension is
+                # contiguous, and the copies were 1 % of a 4K step (27 GB of traffic per decoder chunk).  Price: the whole
+                # chunk tensor stays allocated until the next chunk has consumed the carry.
                 st.mem[name] = None
-                st.mem[name] = x[x.shape[0] - keep:].clone()
+                st.mem[name] = x[x.shape[0] - keep:]
             elif not st.active and x.shape[0] == 1:
                 st.mem[name] = x.expand(keep, -1, -1, -1).contiguous()   # first chunk of one frame: replicas of it
             else:
