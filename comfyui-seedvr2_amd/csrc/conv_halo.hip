@@ -163,118 +163,6 @@ __device__ __forceinline__ void halo_epilogue(const KArgs& a, char* smem, f32x4 
     }
 }
 
-// Direct epilogue of the W-through-registers kernels (round 3): no staging tile in LDS.  W is the MFMA A operand, so a lane's
-// accumulator acc[i][j] already holds four CONSECUTIVE output channels (n0 + cb + 16 j + 4 fq + 0..3) of ONE pixel (row i of the
-// wave's 16 x 16 block, column pi(frow)): the four lanes fq = 0..3 of a pixel write 32 contiguous bytes per j and the waves of a
-// channel row complete the pixel's line, so (acc + bias) is rounded to bf16, the residual (8-byte loads in the same layout,
-// requested before anything else) added, the result rounded and stored from registers: 32 global_store_dwordx2 per lane instead
-// of 32 ds_write_b64 + two barriers + 16 ds_read_b128 + 16 global_store_dwordx4.  Same two roundings in the same order as
-// halo_epilogue: identical outputs.  GroupNorm partial sums: every lane adds its 16 rows per channel, the 16 lanes of a DPP row
-// (same fq, the block's 16 columns) are folded by four xor-shuffles, the WPX waves of a channel column through 2 KiB of LDS, in
-// a fixed order (deterministic; the order differs from halo_epilogue's, so the sums differ from it in fp32 rounding).
-template <int PW, int BN, int MI, int JN>
-__device__ __forceinline__ void halo_epilogue_direct(const KArgs& a, char* smem, f32x4 (&acc)[MI][JN], int wave, int lane, int t,
-                                                     int per_frame, int rem, int y0, int x0, int n0, int cb, int wpx0,
-                                                     int pix, int fq) {
-    constexpr int WPX = PW / 16;
-    const int x = x0 + wpx0 + pix;
-    const bool xok = x < a.cg.Wo;
-    const int nb = n0 + cb + 4 * fq;                       // first channel of j = 0
-    bf16x4 rr[MI][JN];
-    if (a.resid) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int y = y0 + i;
-            const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
-#pragma unroll
-            for (int j = 0; j < JN; ++j) {
-                const int n = nb + j * 16;
-                rr[i][j] = (xok && y < a.cg.Ho && n + 4 <= a.N) ? *(const bf16x4*)(a.resid + m * a.ldr + n) : bf16x4{};
-            }
-        }
-    }
-    f32x4 bv[JN];
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n = nb + j * 16;
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[j][r] = (n + r < a.N) ? a.bias[n + r] : 0.f;
-        }
-    }
-    float st_s[JN][4], st_q[JN][4];
-#pragma unroll
-    for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st_s[j][r] = st_q[j][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int y = y0 + i;
-        const bool ok = xok && y < a.cg.Ho;
-        const long long m = ((long long)t * a.cg.Ho + y) * a.cg.Wo + x;
-#pragma unroll
-        for (int j = 0; j < JN; ++j) {
-            const int n = nb + j * 16;
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r] + bv[j][r]);
-            if (a.resid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(o[r]) + bf2f(rr[i][j][r]));
-            }
-            if (ok) {
-                if (n + 4 <= a.N) *(bf16x4*)(a.C + m * a.ldc + n) = o;
-                else
-                    for (int r = 0; r < a.N - n; ++r) a.C[m * a.ldc + n + r] = o[r];
-                if (a.stats) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = bf2f(o[r]);
-                        st_s[j][r] += v;
-                        st_q[j][r] += v * v;
-                    }
-                }
-            }
-        }
-    }
-    if (a.stats) {   // partial[frame][tile][2][N], folded over tiles by svr2_groupnorm_finalize
-#pragma unroll
-        for (int j = 0; j < JN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) {       // the 16 lanes of a row: same fq, the block's 16 pixel columns
-                    st_s[j][r] += __shfl_xor(st_s[j][r], msk, 64);
-                    st_q[j][r] += __shfl_xor(st_q[j][r], msk, 64);
-                }
-        float* red = (float*)smem;                             // [wave][fq][j][r][2]: 8 x 64 floats
-        asm volatile("s_barrier" ::: "memory");                // every wave is past its last halo read
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int j = 0; j < JN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[((wave * 4 + fq) * JN + j) * 8 + r * 2] = st_s[j][r];
-                    red[((wave * 4 + fq) * JN + j) * 8 + r * 2 + 1] = st_q[j][r];
-                }
-        }
-        __syncthreads();
-        // one thread per (channel of the tile, sum | sumsq): adds the WPX waves of its channel column in wave order
-        constexpr int NWN = 8 / WPX;
-        const int tid = wave * 64 + lane;
-        if (tid < BN * 2) {
-            const int ch = tid >> 1, sq = tid & 1;             // channel inside the tile
-            const int wn_ = ch / (16 * JN), jj = (ch / 16) % JN, q4 = (ch % 16) / 4, r = ch % 4;
-            float tot = 0.f;
-#pragma unroll
-            for (int wm_ = 0; wm_ < WPX; ++wm_) tot += red[(((wm_ * NWN + wn_) * 4 + q4) * JN + jj) * 8 + r * 2 + sq];
-            const int n = n0 + ch;
-            if (n < a.N) a.stats[(((long long)t * per_frame + rem) * 2 + sq) * a.N + n] = tot;
-        }
-    }
-}
-
 template <int PW, int BN>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
@@ -428,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
 //   * SPLIT (small grids, see conv_halo_split): blockIdx.x = tile * S + ks; the workgroup multiplies only the channel
 //     slices [ks * nsl / S, (ks + 1) * nsl / S) and stores its fp32 accumulators as a register image; conv_halo_finish_kernel
 //     adds the S images of a tile in the order ks = 0..S-1 (deterministic) and runs the shared epilogue.
-template <int PW, int BN, bool SPLIT, bool PREF = false, bool DIRECT = false>
+template <int PW, int BN, bool SPLIT, bool PREF = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
     using G = GeoH<PW, BN>;
     constexpr int HP = G::HP, ROWB = G::ROWB, RPI = G::RPI, BK = G::BK;
@@ -611,12 +499,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
             for (int j = 0; j < JN; ++j) img[(i * JN + j) * G::NT] = acc[i][j];
         return;
     }
-    if constexpr (DIRECT) {
-        halo_epilogue_direct<PW, BN, MI, JN>(a, smem, acc, wave, lane, t, per_frame, rem, y0, x0, n0, wn * CPW, wpx0, pix, fq);
-    } else {
-        asm volatile("s_barrier" ::: "memory");
-        halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
-    }
+    // (An epilogue that stores straight from the accumulator layout - four channels of one pixel per lane, 8-byte stores and
+    // residual loads, GroupNorm partial sums by lane shuffles, no LDS tile and two barriers fewer - was built and measured
+    // 0.3-5 % SLOWER, most with a residual: profiles/r03_conv/halodirect_ab.log.  Not kept.)
+    asm volatile("s_barrier" ::: "memory");
+    halo_epilogue<PW, BN, MI, JN>(a, smem, acc, tid, t, per_frame, rem, y0, x0, n0, wn * CPW, 0, wpx0, pix, fq);
 }
 
 // Split convs with many images per tile (S >= 4): the images are added by the whole chip first (one float4 per thread,
@@ -724,11 +611,7 @@ int launch_halo(KArgs a, hipStream_t s) {
             return SVR2_OK;
         }
         a.ks_log2 = 0;
-        // SVR2_HALO_DIRECT (default 1): the epilogue stores from registers (halo_epilogue_direct); 0 = through the LDS tile
-        if (pref && svr2::opt(svr2::OPT_HALO_DIRECT, 1) != 0) {
-            SVR2_SET_MAX_LDS((const void*)(conv_halo_wr_kernel<PW, BN, false, true, true>), G::LDS, "conv_halo (direct)");
-            hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false, true, true>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
-        } else if (pref) {
+        if (pref) {
             SVR2_SET_MAX_LDS((const void*)(conv_halo_wr_kernel<PW, BN, false, true>), G::LDS, "conv_halo (prefetch)");
             hipLaunchKernelGGL((conv_halo_wr_kernel<PW, BN, false, true>), dim3(a.nbm * a.nbn), dim3(G::NT), G::LDS, s, a);
         } else {

@@ -341,9 +341,9 @@ int launch(const KArgs& a, hipStream_t s) {
 namespace svr2 {
 static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
                                                  "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V",
-                                                 "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT", "SVR2_ATTN5_V", "SVR2_HALO_PREF", "SVR2_HALO_DIRECT"};
+                                                 "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT", "SVR2_ATTN5_V", "SVR2_HALO_PREF"};
 static const int kUnset = INT32_MIN;
-static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
 static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
 
 int opt(Opt o, int dflt) {

@@ -46,8 +46,7 @@ int svr2_device_check(int dev);
 /* Tuning switches for A/B measurements and tests (never needed in production): name is one of SVR2_HALO_WR,
  * SVR2_GEMM_V, SVR2_GEMM4, SVR2_GEMM_BM, SVR2_GEMM2_NARROW, SVR2_CONV_LINEAR_TILES, SVR2_ATTN_V (1 = the plain window-attention kernel, bit-identical to the default), SVR2_ATTN5_V (0 = attn_d512 without the
  * software-pipelined fragment schedule, bit-identical),
- * SVR2_HALO_PREF (0 = halo conv without the fragment prefetch, bit-identical), SVR2_HALO_DIRECT (0 = its epilogue through the
- * LDS tile instead of from registers: same outputs, GroupNorm partial sums equal up to fp32 summation order), SVR2_CONV_TFAST (frame-fastest conv tile order), SVR2_CONV_SPLIT (0: never split a conv along K); unset != 0 returns
+ * SVR2_HALO_PREF (0 = halo conv without the fragment prefetch, bit-identical), SVR2_CONV_TFAST (frame-fastest conv tile order), SVR2_CONV_SPLIT (0: never split a conv along K); unset != 0 returns
  * the switch to its built-in default.  Switches never change results beyond fp32 summation order. */
 int svr2_set_option(const char* name, int value, int unset);
 

@@ -226,19 +226,6 @@ if __name__ == "__main__":
                 bench_conv(4, 1080, 1920, 512, 512, tiled=True)
                 bench_conv(5, 272, 480, 512, 512, tiled=True)
         hip.set_option("SVR2_HALO_PREF", None)
-    if "halodirect" in which:   # same-process A/B of the register epilogue (SVR2_HALO_DIRECT), with GroupNorm partial sums
-        os.environ["SVR2_KB_GNSTATS"] = "1"
-        for rnd in range(3):
-            for v in (0, 1):
-                hip.set_option("SVR2_HALO_DIRECT", v)
-                print(f"-- round {rnd} SVR2_HALO_DIRECT={v}", flush=True)
-                bench_conv(4, 2160, 3840, 128, 128, tiled=True)
-                bench_conv(4, 2160, 3840, 128, 128, tiled=True, resid=True)
-                bench_conv(4, 2160, 3840, 256, 128, tiled=True)
-                bench_conv(4, 2160, 3840, 256, 256, tiled=True)
-                bench_conv(4, 1080, 1920, 256, 256, tiled=True, resid=True)
-                bench_conv(4, 1080, 1920, 512, 512, tiled=True)
-        hip.set_option("SVR2_HALO_DIRECT", None)
     if "halopmc" in which:   # few launches of the three dominant halo-conv shapes for counter collection
         bench_conv(4, 2160, 3840, 128, 128, tiled=True)
         bench_conv(4, 1080, 1920, 256, 256, tiled=True)
