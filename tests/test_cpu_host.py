@@ -225,4 +225,4 @@ def test_no_timing_variant_code_in_product_sources():
         text = open(f).read()
         assert "_DBG" not in text.replace("_dbg.patch", ""), f
     for p in glob.glob(os.path.join(ge.ROOT, "tools", "timing_variants", "*.patch")):
-        assert "_DBG" in open(p).read()
+        assert "WRONG results" in open(p).read(), p           # every variant says what it is
