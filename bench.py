@@ -42,6 +42,7 @@ WORKLOADS = {
     "cfg2": ("3b", 8, 9, 540, 960, 1080, 0, "SeedVR2-3B bf16, 8-frame (padded to 9) 540p->1080p (BASELINE configs[1])"),
     "cfg1": ("3b", 1, 1, 256, 256, 512, 0, "SeedVR2-3B bf16, single 256x256 image x2 (BASELINE configs[0])"),
     "cfg2o": ("3b", 26, 9, 540, 960, 1080, 4, "rehearsal: 540p->1080p clip of 26 frames, batch 9, overlap 4 (exercises blend + neighbour exchange)"),
+    "cfg3t65": ("3b", 65, 65, 720, 1280, 2160, 0, "memory rehearsal: ONE batch of 65 frames 720p->4K (DiT grid (17,135,240), 550 800 tokens: SURVEY 8's largest grid)"),
     "cfg0": ("3b", 26, 9, 32, 48, 64, 4, "rehearsal of the launcher / exchange / JSON contract: 32x48 -> 64x96 clip of 26 frames, batch 9, overlap 4"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
