@@ -1,9 +1,9 @@
 #!/bin/bash
 # Window-attention measurement on the GPU box: same-process A/B timing of the SVR2_ATTN_V variants, then rocprofv3 PMC
 # passes per variant (counters only with --kernel-trace; FETCH_SIZE / WRITE_SIZE in passes of their own).
-#   usage: tools/profile_attn.sh <tag> "<versions, e.g. 1,2,3>"
+#   usage: tools/profile_attn.sh <tag> "<versions: 5 = default kernel, 1 = the plain kernel of the same geometry>"
 set -e -o pipefail
-TAG=${1:-r02}; VERS=${2:-1,2}
+TAG=${1:-r03}; VERS=${2:-1,5}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/attn_$TAG
 mkdir -p $OUT
