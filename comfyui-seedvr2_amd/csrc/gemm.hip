@@ -20,14 +20,12 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int B_TILE_BYTES = BN * BK * 2;         // 16 KiB
-// Three geometries share one kernel body (template parameters BM, ST = depth of the LDS ring):
+// Two geometries share one kernel body (template parameters BM, ST = depth of the LDS ring):
 //   BM = 128, ST 2: 4 waves (2 x 2), 2-deep LDS ring (64 KiB), 2 workgroups per CU  - small problems / tails
 //   BM = 256, ST 3: 8 waves (4 x 2), 3-deep LDS ring (144 KiB), counted vmcnt: two K-tiles of DMA stay in flight
 //             across the barrier, W traffic per FLOP halves                          - the large GEMMs / convs
-//   BM = 128, ST 4: the 128-row tile with a 4-deep ring (128 KiB, one workgroup per CU) and three K-tiles of DMA in
-//             flight - for tile-starved problems (at most one workgroup per CU anyway, e.g. the M = 1024 projections
-//             of a 512 x 512 image: 160 tiles on 256 CUs), where the 2-deep ring makes every K-step wait for a whole
-//             LDS-DMA round trip (measured 0.85 us per 64-deep step against 0.25 us of MFMA work)
+//   (a BM = 128, ST 4 form - 4-deep ring for tile-starved problems - was measured at no gain in round 2 and is no longer
+//   dispatched: those shapes are bound by the rate at which a CU accepts 1-KiB LDS-DMA pieces, 32 per 128 x 128 x 64 step)
 template <int BM, int ST> struct Geo {
     static constexpr int NT = BM * 2;                       // threads
     static constexpr int NW = NT / 64;                      // waves
