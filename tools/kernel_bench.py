@@ -162,6 +162,13 @@ if __name__ == "__main__":
         bench_conv(5, 272, 480, 512, 512)
         bench_conv(4, 2160, 3840, 128, 128)
         bench_attn((5, 135, 240), pkg.windows.REGULAR)
+    if "stalls" in which:  # one shape of each big MFMA kernel for the stall-counter passes (tools/profile_stalls.sh)
+        bench_conv(4, 1080, 1920, 512, 512, tiled=True)     # conv_halo_wr<16,256>
+        bench_conv(4, 2160, 3840, 128, 128, tiled=True)     # conv_halo_wr<32,128>
+        bench_gemm(194400, 7680, 2560)                      # gemm4 (qkv)
+        bench_gemm(194400, 2560, 6912, "gate")              # gemm4 (ffn_out)
+        os.environ["SVR2_KB_ATTN5_VARS"] = "1"
+        bench_attn512(1, 129600)
     if "gemmsmallm" in which:   # the NaDiT-3B projections of a 512 x 512 image (M = 1024 tokens): tile-starved
         for r in range(3):
             bench_gemm(1024, 7680, 2560)
