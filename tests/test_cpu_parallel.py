@@ -90,3 +90,26 @@ def test_segment_ranges_reference_split(pkg):
     assert P.segment_ranges(10, 1, 4) == [(0, 10)]
     # pre-loaded split rounds the chunk up to a multiple of batch_size [ref: inference_cli.py:1118-1133]
     assert P.segment_ranges(100, 2, 4, batch_size=5, streaming=False) == [(0, 55), (51, 100)]
+
+
+def test_counts_are_local_arithmetic_and_checked_before_any_communication(pkg):
+    """Round 3: no count exchange.  owned_counts restates the reference's concatenation rule (later chunks contribute
+    chunk[overlap:], nothing when chunk.shape[0] <= overlap, inference_cli.py:1163-1198); a rank whose frame count contradicts
+    the segment plan raises BEFORE it touches the process group, so it cannot leave a neighbour waiting on a half-made exchange."""
+    P = pkg.parallel
+    assert P.owned_counts([68, 68, 64], 4) == [68, 64, 60]
+    assert P.owned_counts([10, 3, 9], 4) == [10, 0, 5]
+    assert P.owned_counts([7, 7], 0) == [7, 7]
+
+    class NoDist:                       # any use of the process group fails the test
+        def __getattr__(self, name):
+            raise AssertionError(f"dist.{name} used")
+
+    frames = torch.zeros(5, 2, 2, 3)
+    with pytest.raises(ValueError):
+        P.exchange_and_blend(frames, 2, 0, 2, NoDist(), counts=[6, 9])
+    with pytest.raises(ValueError):
+        P.gather_frames(frames, 1, 2, 0, NoDist(), counts=[5, 4])
+    # world 1 / no overlap: nothing to exchange, the frames come back as they are
+    assert P.exchange_and_blend(frames, 2, 0, 1, NoDist()) is frames
+    assert P.exchange_and_blend(frames, 0, 1, 2, NoDist()) is frames
