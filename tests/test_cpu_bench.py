@@ -64,3 +64,18 @@ def test_single_rank_and_wrong_world_size():
 def test_a_dead_rank_ends_the_bench_non_zero():
     lines, r = _run(["--gpus", "2", "--workload", "cfg0", "--no-cpu-baseline"], {"SVR2_TEST_FAIL_RANK": "1"}, expect_rc=1)
     assert not lines and "exit codes" in r.stderr
+
+
+def test_eight_ranks_strong_scaling_with_the_references_edge_case():
+    """--gpus 8 (the driver's largest run) through the self-launch: 26 frames over 8 ranks -> segments of 3 or 4 (+4 overlap,
+    clipped at the clip's end) frames; the last rank holds 3 <= overlap frames, which the reference's concatenation drops
+    (inference_cli.py:1163-1198) - they are already inside its left neighbour's clipped overlap: the exchange must neither
+    hang nor lose or double-count a frame."""
+    lines, _ = _run(["--gpus", "8", "--workload", "cfg0", "--steps", "2", "--warmup", "1", "--scaling", "strong",
+                     "--no-cpu-baseline"])
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8
+    assert c["segment_frames_by_rank"] == [8, 8, 7, 7, 7, 7, 6, 3] and c["clip_frames_total"] == 26
+    owned = [8] + [s - 4 if s > 4 else 0 for s in c["segment_frames_by_rank"][1:]]
+    assert c["finished_frames"] == 2 * sum(owned) == 2 * 26
