@@ -226,3 +226,18 @@ def test_no_timing_variant_code_in_product_sources():
         assert "_DBG" not in text.replace("_dbg.patch", ""), f
     for p in glob.glob(os.path.join(ge.ROOT, "tools", "timing_variants", "*.patch")):
         assert "WRONG results" in open(p).read(), p           # every variant says what it is
+
+
+def test_timing_variant_patches_still_apply_to_the_product_sources():
+    """tools/build_timing_variant.py applies each patch to a copy of csrc/: a kernel edit that breaks one shows up here."""
+    import glob
+    import shutil
+    import subprocess
+    import __graft_entry__ as ge
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1)")
+    for p in sorted(glob.glob(os.path.join(ge.ROOT, "tools", "timing_variants", "*.patch"))):
+        with open(p) as fh:
+            target = os.path.join(ge.PKG_DIR, "csrc", os.path.basename(fh.readline().split()[1]))
+        r = subprocess.run(["patch", "--dry-run", "-s", target, p], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stdout, r.stderr)
