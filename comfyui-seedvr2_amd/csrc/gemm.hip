@@ -24,8 +24,9 @@ constexpr int B_TILE_BYTES = BN * BK * 2;         // 16 KiB
 //   BM = 128, ST 2: 4 waves (2 x 2), 2-deep LDS ring (64 KiB), 2 workgroups per CU  - small problems / tails
 //   BM = 256, ST 3: 8 waves (4 x 2), 3-deep LDS ring (144 KiB), counted vmcnt: two K-tiles of DMA stay in flight
 //             across the barrier, W traffic per FLOP halves                          - the large GEMMs / convs
-//   (a BM = 128, ST 4 form - 4-deep ring for tile-starved problems - was measured at no gain in round 2 and is no longer
-//   dispatched: those shapes are bound by the rate at which a CU accepts 1-KiB LDS-DMA pieces, 32 per 128 x 128 x 64 step)
+//   BM = 128, ST 3: the 128-row tile with a 3-deep ring (96 KiB, one workgroup per CU) - tile-starved dense GEMMs whose
+//             weights come from HBM (round 2 measured a deeper ring at no gain, but on a replayed, cache-hot weight;
+//             round 3 with weights rotated through 300 MB: -19...-24 %, see launch())
 template <int BM, int ST> struct Geo {
     static constexpr int NT = BM * 2;                       // threads
     static constexpr int NW = NT / 64;                      // waves
@@ -328,8 +329,21 @@ int launch(const KArgs& a, hipStream_t s) {
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;
     if (big) return launch_bm<AMODE, EPI, 256, 3>(a, s);
-    // (a 4-deep ring for tile-starved dense problems was measured at no gain - those shapes are bound by the rate at
-    // which a CU accepts 1-KiB LDS-DMA pieces, not by the DMA latency a deeper ring hides - and is gone: DESIGN 3.2)
+    // Tile-starved dense GEMMs with a long K loop (the NaDiT projections of a small image: M ~ 1 000 tokens, and the
+    // text lane's M = 58): at most one workgroup per CU, so the LDS a second workgroup would have used buys a third ring
+    // stage.  With weights that come from HBM (a layer's weights are never cache-hot in the pipeline) the 2-deep ring
+    // waits a memory round trip per K-step: measured 44.4 -> 35.9 us (N = K = 2 560) and 98 -> 74.5 us (K = 6 912) at
+    // M = 1 024; a 4th and 5th stage add nothing (profiles/r03_gemm_small_m.log).  Same K order: bit-identical results.
+    // When 128-row tiles would need a second round but 256-row tiles fit in one (qkv at M = 1 024: 480 vs 240 tiles),
+    // one 256-row workgroup per CU moves 25 % fewer bytes per CU than two 128-row ones: 55.4 -> 51.5 us.
+    // SVR2_GEMM_BM=128 keeps the 2-deep geometry for A/B runs.
+    if constexpr (AMODE == A_DENSE) {
+        const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (g_force_bm() != 128 && a.K >= 1024) {
+            if (tiles1 <= 256) return launch_bm<AMODE, EPI, 128, 3>(a, s);
+            if (tiles2 <= 256) return launch_bm<AMODE, EPI, 256, 3>(a, s);
+        }
+    }
     return launch_bm<AMODE, EPI, 128, 2>(a, s);
 }
 

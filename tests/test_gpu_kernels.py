@@ -35,6 +35,32 @@ def test_gemm_bias(pkg, gpu, M, N, K):
     assert_close(out, a @ w.T + b, f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 2560, 2560, "gate"), (58, 2560, 6912, "gate"), (1024, 7680, 2560, "bias"),
+                                       (1000, 7680, 1024, "gelu"), (58, 13824, 2560, "swiglu")])
+def test_tile_starved_gemm_geometries_bit_identical_to_the_two_deep_ring(pkg, gpu, M, N, K, epi, lib_option):
+    """Tile-starved dense GEMMs (<= 256 tiles, K >= 1024) take a 3-deep LDS ring, or one 256-row workgroup per CU when
+    128-row tiles would need a second round (gemm.hip launch()): same K order as the 2-deep 128-row geometry that
+    SVR2_GEMM_BM=128 keeps, so the results are the same bits.  [ref: F.linear calls of mmattn.py:173,269, mlp.py:60-61]"""
+    hip = pkg.hip
+    a, w = dev_bf16(rnd(M, K, seed=1), gpu), hip.pad_weight(rnd(N, K, seed=2, scale=1 / math.sqrt(K)).to(gpu))
+    bias, gate, res = rnd(N, seed=3).to(gpu), rnd(N, seed=4).to(gpu), dev_bf16(rnd(M, N, seed=5), gpu)
+
+    def run():
+        if epi == "gate":
+            return hip.gemm(a, w, N, epilogue=hip.EPI_GATE_RES, bias=bias, gate=gate, resid=res, m=M)
+        if epi == "gelu":
+            return hip.gemm(a, w, N, epilogue=hip.EPI_GELU, bias=bias)
+        if epi == "swiglu":
+            return hip.gemm(a, w, N, epilogue=hip.EPI_SWIGLU)
+        return hip.gemm(a, w, N, bias=bias)
+
+    got = run()
+    lib_option("SVR2_GEMM_BM", 128)
+    want = run()
+    assert torch.isfinite(got.float()).all() and got.float().abs().max() > 0
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 512, 384), (777, 2560, 2560), (256, 256, 6912), (513, 768, 192)])
 def test_gemm4_pingpong_bias(pkg, gpu, M, N, K, lib_option):
     """gemm4.hip (ping-pong 256x256x64 kernel, five LDS sub-stages): forced onto small shapes with SVR2_GEMM_V=3."""

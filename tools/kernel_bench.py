@@ -176,6 +176,44 @@ if __name__ == "__main__":
             bench_gemm(1024, 13824, 2560, "swiglu")
             bench_gemm(1024, 2560, 6912, "gate")
             bench_gemm(58, 2560, 2560, "gate")
+    if "gemmsmallm_ab" in which:   # the same projections under every tile geometry the dispatcher can pick, weights rotated
+        # through > 256 MB of copies (a layer's weights are never cache-hot in the pipeline), hipBLASLt beside them
+        shapes = [("qkv", 1024, 7680, 2560, "bias"), ("out", 1024, 2560, 2560, "gate"),
+                  ("ffn_in", 1024, 13824, 2560, "swiglu"), ("ffn_out", 1024, 2560, 6912, "gate")]
+        settings = [("default", {}), ("bm256", {"SVR2_GEMM_BM": 256}), ("gemm4", {"SVR2_GEMM_V": 3}),
+                    ("bm128_2deep", {"SVR2_GEMM_BM": 128, "SVR2_GEMM_V": 1}),
+                    ("gemm2_256x256", {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0}),
+                    ("gemm2_256x128", {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0, "SVR2_GEMM2_NARROW": 1})]
+        for name, M, N, K, epi in shapes:
+            ncopy = max(2, int(300e6 // (N * K * 2)) + 1)
+            a = rb(M, K)
+            ws = [hip.pad_weight(rb(N, K, scale=1 / math.sqrt(K))) for _ in range(ncopy)]
+            wt = [w[:N].t() for w in ws]
+            out = torch.empty(M, N if epi != "swiglu" else N // 2, dtype=torch.bfloat16, device=dev)
+            res, gate = rb(M, N), torch.randn(N, device=dev)
+            it = [0]
+            def call():
+                w = ws[it[0] % ncopy]; it[0] += 1
+                if epi == "bias":
+                    hip.gemm(a, w, N, out)
+                elif epi == "swiglu":
+                    hip.gemm(a, w, N, out, epilogue=hip.EPI_SWIGLU)
+                else:
+                    hip.gemm(a, w, N, out, epilogue=hip.EPI_GATE_RES, gate=gate, resid=res, m=M)
+            def lib_call():
+                w = wt[it[0] % ncopy]; it[0] += 1
+                torch.matmul(a, w)
+            for r in range(2):
+                for sname, opts in settings:
+                    for k, v in opts.items():
+                        hip.set_option(k, v)
+                    t = timeit(call, iters=10 * ncopy, warm=ncopy)
+                    for k in opts:
+                        hip.set_option(k, None)
+                    print(f"{name} M={M} N={N} K={K} [{sname}]: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.0f} TFLOP/s", flush=True)
+                t = timeit(lib_call, iters=10 * ncopy, warm=ncopy)
+                print(f"{name} M={M} N={N} K={K} [torch.matmul, no epilogue]: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.0f} TFLOP/s", flush=True)
+            del ws, wt
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
