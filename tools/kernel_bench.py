@@ -180,6 +180,9 @@ if __name__ == "__main__":
         # through > 256 MB of copies (a layer's weights are never cache-hot in the pipeline), hipBLASLt beside them
         shapes = [("qkv", 1024, 7680, 2560, "bias"), ("out", 1024, 2560, 2560, "gate"),
                   ("ffn_in", 1024, 13824, 2560, "swiglu"), ("ffn_out", 1024, 2560, 6912, "gate")]
+        if os.environ.get("SVR2_KB_SHAPES"):     # name:M:N:K:epi,...
+            shapes = [(f[0], int(f[1]), int(f[2]), int(f[3]), f[4]) for f in
+                      (t.split(":") for t in os.environ["SVR2_KB_SHAPES"].split(","))]
         settings = [("default", {}), ("bm256", {"SVR2_GEMM_BM": 256}), ("gemm4", {"SVR2_GEMM_V": 3}),
                     ("bm128_2deep", {"SVR2_GEMM_BM": 128, "SVR2_GEMM_V": 1}),
                     ("gemm2_256x256", {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0}),
@@ -214,6 +217,26 @@ if __name__ == "__main__":
                 t = timeit(lib_call, iters=10 * ncopy, warm=ncopy)
                 print(f"{name} M={M} N={N} K={K} [torch.matmul, no epilogue]: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.0f} TFLOP/s", flush=True)
             del ws, wt
+    if "convsmall_cold" in which:   # the VAE's 3x3x3 convs of ONE 512 x 512 frame (cfg1), replayed on one weight (cache-hot)
+        # and with the weight rotated through > 300 MB of copies (what the pipeline sees: every layer has its own)
+        for (H, W, Cin, Cout) in ((64, 64, 512, 512), (128, 128, 512, 512), (256, 256, 256, 256), (512, 512, 128, 128)):
+            x = rb(1, H, W, Cin)
+            ncopy = max(2, int(300e6 // (Cout * Cin * 27 * 2)) + 1)
+            ws = [hip.conv_weight_tiled(rb(Cout, Cin, 3, 3, 3, scale=0.02)) for _ in range(ncopy)]
+            b = torch.zeros(Cout, device=dev)
+            out = torch.empty(1, H, W, Cout, dtype=torch.bfloat16, device=dev)
+            it = [0]
+            def call(rot):
+                w = ws[it[0] % ncopy if rot else 0]; it[0] += 1
+                hip.conv3d(x, w, Cout, (3, 3, 3), npad=2, pad_hw=(1, 1, 1, 1), bias=b, out=out, w_layout=hip.WL_TILED_128x32,
+                           gn_stats=True)
+            fl = 2 * H * W * Cin * Cout * 27
+            for r in range(2):
+                th = timeit(lambda: call(False), iters=10 * ncopy, warm=ncopy)
+                tc = timeit(lambda: call(True), iters=10 * ncopy, warm=ncopy)
+                print(f"conv {H}x{W} {Cin}->{Cout}: hot {th*1e6:.1f} us ({fl/th/1e12:.0f} TFLOP/s)  cold {tc*1e6:.1f} us "
+                      f"({fl/tc/1e12:.0f} TFLOP/s)  x{tc/th:.2f}", flush=True)
+            del ws
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
