@@ -320,8 +320,12 @@ int launch(const KArgs& a, hipStream_t s) {
     // the K = 256..512 GEMMs of the VAE)
     // the row-gathered proj_out GEMM stays on gemm2: scattered rows make its DMA pieces cost the two A-streaming waves of a
     // group more than a LOAD phase has - measured 535 vs 850 TFLOP/s)
+    // from where on: one round of the 128-row kernel is 512 workgroups (two per CU); past that a second round starts and one
+    // round of 256 x 256 ping-pong tiles is faster although it fills fewer CUs (M = 3 328, N = K = 2 560: 90 -> 82 us; NaDiT-7B
+    // qkv at M = 1 024: 98 -> 67 us; below 512 tiles the 128-row kernel wins by 30-45 %: profiles/r03_gemm_small_m.log)
+    const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (AMODE == A_DENSE && a.N % 256 == 0 && a.K % 64 == 0 &&
-        ((a.K >= 1024 && tiles2 >= 384 && !a.a_rows) || (ver == 3 && a.K >= 128))) {
+        ((a.K >= 1024 && tiles1 > 512 && !a.a_rows) || (ver == 3 && a.K >= 128))) {
         if (svr2::opt(svr2::OPT_GEMM4, 1) != 0) return gemm4_launch(EPI, a, s);
     }
     const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.cg.Cin <= 128 && a.N == 128);
@@ -334,14 +338,14 @@ int launch(const KArgs& a, hipStream_t s) {
     // stage.  With weights that come from HBM (a layer's weights are never cache-hot in the pipeline) the 2-deep ring
     // waits a memory round trip per K-step: measured 44.4 -> 35.9 us (N = K = 2 560) and 98 -> 74.5 us (K = 6 912) at
     // M = 1 024; a 4th and 5th stage add nothing (profiles/r03_gemm_small_m.log).  Same K order: bit-identical results.
-    // When 128-row tiles would need a second round but 256-row tiles fit in one (qkv at M = 1 024: 480 vs 240 tiles),
-    // one 256-row workgroup per CU moves 25 % fewer bytes per CU than two 128-row ones: 55.4 -> 51.5 us.
+    // Where two 128-row workgroups per CU would share a CU but 256-row tiles fit one per CU, and the weight is the big
+    // operand (N >= 4 M: qkv at M = 1 024, 480 vs 240 tiles), one 256-row workgroup moves 25 % fewer bytes per CU:
+    // 55.4 -> 51.5 us; with M comparable to N it is no faster (M = 2 560 ... 3 072, N = 2 560: 58 vs 54-56 us).
     // SVR2_GEMM_BM=128 keeps the 2-deep geometry for A/B runs.
     if constexpr (AMODE == A_DENSE) {
-        const long long tiles1 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (g_force_bm() != 128 && a.K >= 1024) {
             if (tiles1 <= 256) return launch_bm<AMODE, EPI, 128, 3>(a, s);
-            if (tiles2 <= 256) return launch_bm<AMODE, EPI, 256, 3>(a, s);
+            if (tiles2 <= 256 && a.N >= 4 * a.M) return launch_bm<AMODE, EPI, 256, 3>(a, s);   // W-dominated only
         }
     }
     return launch_bm<AMODE, EPI, 128, 2>(a, s);
