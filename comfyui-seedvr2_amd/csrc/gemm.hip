@@ -506,6 +506,18 @@ extern "C" int64_t svr2_conv3d_split_ws_bytes(const svr2_conv3d_desc* d) {
 
 extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
+    if (d->w_layout == SVR2_WL_CIN3) {   // fused conv_in (conv_in.hip)
+        SVR2_CHECK(d->Cin == 3 && d->Cout == 128 && d->kt == 3 && conv_halo_shape(d) && d->npad == 2 && d->To == d->T &&
+                       d->T >= 1 && d->Hi >= 1 && d->Wi >= 1,
+                   SVR2_E_SHAPE, "svr2_conv3d: SVR2_WL_CIN3 needs Cin 3, Cout 128, 3x3x3, stride 1, pad 1, npad 2");
+        SVR2_CHECK(!d->resid, SVR2_E_ARG, "svr2_conv3d: SVR2_WL_CIN3 has no residual input");
+        SVR2_CHECK(aligned16(d->w) && aligned16(d->y) && (((uintptr_t)d->x) & 1) == 0 &&
+                       (!d->carry || (((uintptr_t)d->carry) & 1) == 0),
+                   SVR2_E_ALIGN, "svr2_conv3d: SVR2_WL_CIN3 needs 16-byte aligned w and y");
+        SVR2_CHECK((long long)d->To * d->Ho * d->Wo < (1ll << 31) - 256, SVR2_E_SHAPE,
+                   "svr2_conv3d: too many output pixels for one call");
+        return conv_in3_launch(d, (hipStream_t)stream);
+    }
     const bool tiled = d->w_layout == SVR2_WL_TILED_128x32;
     SVR2_CHECK(d->w_layout == SVR2_WL_ROWS || tiled, SVR2_E_ARG, "svr2_conv3d: unknown w_layout %d", d->w_layout);
     SVR2_CHECK(d->Cin > 0 && d->Cin % (tiled ? 32 : BK) == 0, SVR2_E_SHAPE,

@@ -146,6 +146,7 @@ int gemm4_launch(int epi, KArgs a, hipStream_t s);
 int gemm2_launch(int amode, int epi, KArgs a, hipStream_t s);
 // implemented in conv_halo.hip: halo-resident stride-1 3x3(xkt) conv
 int conv_halo_launch(KArgs a, hipStream_t s);
+int conv_in3_launch(const svr2_conv3d_desc* d, hipStream_t s);   // conv_in.hip
 size_t conv_halo_split_bytes(const KArgs& a);
 
 }  // namespace svr2

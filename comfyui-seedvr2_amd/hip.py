@@ -200,7 +200,20 @@ def conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(cout, cin // 64, 64, kt, kh, kw).permute(0, 3, 1, 4, 5, 2).reshape(cout, kt * kh * kw * cin)
 
 
-WL_ROWS, WL_TILED_128x32 = 0, 1
+WL_ROWS, WL_TILED_128x32, WL_CIN3 = 0, 1, 2
+
+
+def conv_weight_cin3(w: torch.Tensor) -> torch.Tensor:
+    """Reference conv_in weight [128, 3, 3, 3, 3] -> SVR2_WL_CIN3 (include/seedvr2_hip.h): bf16 [128, 128] with
+    k = (kt*3 + ky)*12 + kx*4 + c; the pad channel c = 3 and k >= 108 are zero."""
+    cout, cin, kt, kh, kw = w.shape
+    if (cout, cin, kt, kh, kw) != (128, 3, 3, 3, 3):
+        raise HipError(f"conv_weight_cin3: expected [128,3,3,3,3], got {tuple(w.shape)}")
+    t = torch.zeros(cout, kt, kh, kw, 4, dtype=torch.bfloat16, device=w.device)
+    t[..., :3] = w.to(torch.bfloat16).permute(0, 2, 3, 4, 1)                  # [cout, kt, ky, kx, c]
+    out = torch.zeros(cout, 128, dtype=torch.bfloat16, device=w.device)
+    out[:, :108] = t.reshape(cout, 108)
+    return out
 
 
 def conv_weight_tiled(w: torch.Tensor) -> torch.Tensor:
@@ -321,13 +334,17 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
            resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            w_layout: int = WL_ROWS, gn_stats: bool = False):
     """Causal NDHWC conv.  x [T,Hi,Wi,Cin] bf16; w = pad_weight(conv_weight(w5d)) ([cout_pad, kt*kh*kw*Cin]), or
-    conv_weight_tiled(w5d) with w_layout = WL_TILED_128x32.  gn_stats (tiled layout only): also return the per-tile
-    GroupNorm partial sums of the output, (out, GnPartial), for groupnorm_silu(..., partial=...)."""
+    conv_weight_tiled(w5d) with w_layout = WL_TILED_128x32, or conv_weight_cin3(w5d) with WL_CIN3 (the fused Cin = 3
+    conv_in).  gn_stats (tiled and Cin-3 layouts): also return the per-tile GroupNorm partial sums of the output,
+    (out, GnPartial), for groupnorm_silu(..., partial=...)."""
     _bf16c(x, "conv3d.x"); _bf16c(w, "conv3d.w")
     if x.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
         raise HipError("conv3d: x must be contiguous [T,H,W,C]")
     T, Hi, Wi, Cin = x.shape
-    if w.shape[1] != k[0] * k[1] * k[2] * Cin or w.shape[0] % 128 or w.shape[0] < cout:
+    if w_layout == WL_CIN3:
+        if tuple(w.shape) != (128, 128) or Cin != 3 or cout != 128 or tuple(k) != (3, 3, 3) or resid is not None:
+            raise HipError(f"conv3d: WL_CIN3 is the 3 -> 128 channel 3x3x3 conv without residual (Cin={Cin} cout={cout} k={k})")
+    elif w.shape[1] != k[0] * k[1] * k[2] * Cin or w.shape[0] % 128 or w.shape[0] < cout:
         raise HipError(f"conv3d: weight shape {tuple(w.shape)} does not match k={k} Cin={Cin} cout={cout}")
     if carry is not None:
         _bf16c(carry, "conv3d.carry")
@@ -345,8 +362,8 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
         raise HipError("conv3d: resid must match the output shape")
     part = None
     if gn_stats:
-        if w_layout != WL_TILED_128x32:
-            raise HipError("conv3d: gn_stats needs the tiled weight layout")
+        if w_layout not in (WL_TILED_128x32, WL_CIN3):
+            raise HipError("conv3d: gn_stats needs the tiled or the Cin-3 weight layout")
         lib().svr2_conv3d_gn_tiles.restype = C.c_int32
         tiles = int(lib().svr2_conv3d_gn_tiles(C.c_int32(Ho), C.c_int32(Wo), C.c_int32(cout)))
         part = GnPartial(torch.empty(To, tiles, 2, cout, dtype=torch.float32, device=x.device), tiles)

@@ -18,6 +18,7 @@ Weights are taken in the reference's state-dict layout ([Cout, Cin, kt, kh, kw] 
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -67,6 +68,7 @@ class VideoVAEHip:
         self.cfg = cfg
         self.device = torch.device(device)
         dev = self.device
+        self.fused_conv_in = os.environ.get("SVR2_CONV_IN_FUSED", "1") != "0"      # A/B switch, resolved once
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.convs: Dict[str, dict] = {}
         self.norms: Dict[str, tuple] = {}
@@ -80,9 +82,12 @@ class VideoVAEHip:
                     # the K layout depends on the kernel that will run the layer (stride / padding are call-site
                     # facts): built on first use by _conv_weight(), then the 5-D copy is dropped
                     ent["w5"] = v.detach().to(device=dev, dtype=torch.bfloat16)
-                else:  # small-Cin layers (3, 16): explicit im2col + GEMM
+                else:  # small-Cin layers (3, 16): explicit im2col + GEMM ...
                     ent["kpad"] = (kt * kh * kw * cin + 63) // 64 * 64
                     ent["w"] = hip.pad_weight(hip.conv_weight(v.detach().to(dev)), ent["kpad"])
+                    if (cout, cin, kt, kh, kw) == (128, 3, 3, 3, 3) and self.fused_conv_in:
+                        # ... except the encoder's conv_in, which has a fused kernel (csrc/conv_in.hip): no column matrix
+                        ent["w_cin3"] = hip.conv_weight_cin3(v.detach().to(dev))
                 self.convs[name] = ent
             elif k.endswith(".weight") and v.dim() == 1:
                 name = k[: -len(".weight")]
@@ -119,7 +124,11 @@ class VideoVAEHip:
             carry, npad = st.mem[name], keep
         else:
             carry, npad = None, 2 * ((kt - 1) // 2)  # first chunk: replicate frame 0  [ref: causal_inflation_lib.py:422-437]
-        if "kpad" in c:
+        if "w_cin3" in c and tuple(stride) == (1, 1, 1) and tuple(pad_hw) == (1, 1, 1, 1) and npad == 2 and resid is None:
+            y, part = hip.conv3d(x, c["w_cin3"], c["cout"], c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry,
+                                 bias=c["bias"], w_layout=hip.WL_CIN3, gn_stats=True)
+            st.stats = (y, part)
+        elif "kpad" in c:
             col = hip.im2col3d(x, c["k"], stride, npad=npad, pad_hw=pad_hw, carry=carry, kpad=c["kpad"])
             to, ho, wo = hip.conv_out_size(x.shape[0], x.shape[1], x.shape[2], c["k"], stride, npad, pad_hw)
             y = hip.gemm(col, c["w"], c["cout"], bias=c["bias"]).view(to, ho, wo, c["cout"])

@@ -111,8 +111,13 @@ int svr2_gemm(const svr2_gemm_desc* d, void* stream);
  *   tiles of one kx column are 24 contiguous KiB) where each [128][32] tile is stored in LDS-image order: the
  *   16-byte chunk at (row r, slot s) holds channels 8*(s ^ f(r)) .. +8, f(r) = {0,2,3,1}[(r >> 2) & 3]
  *   (every weight DMA is then one linear KiB).
+ *
+ *   w_layout = SVR2_WL_CIN3 selects the fused kernel of the encoder's conv_in (conv_in.hip): Cin = 3, Cout = 128,
+ *   3x3x3, stride 1, zero padding 1, npad = 2, no residual; x and carry are bf16 [.., Hi, Wi, 3] (6 bytes per pixel),
+ *   w is bf16 [128][128] with k = (kt*3 + ky)*12 + kx*4 + c (c = 3 and k >= 108 zero).  gn_partial as for the tiled layout
+ *   (same tile geometry).  Replaces svr2_im2col3d + svr2_gemm for this layer: no column matrix is written.
  */
-enum { SVR2_WL_ROWS = 0, SVR2_WL_TILED_128x32 = 1 };
+enum { SVR2_WL_ROWS = 0, SVR2_WL_TILED_128x32 = 1, SVR2_WL_CIN3 = 2 };
 
 typedef struct svr2_conv3d_desc {
     const void* x;

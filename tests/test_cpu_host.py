@@ -241,3 +241,17 @@ def test_timing_variant_patches_still_apply_to_the_product_sources():
             target = os.path.join(ge.PKG_DIR, "csrc", os.path.basename(fh.readline().split()[1]))
         r = subprocess.run(["patch", "--dry-run", "-s", target, p], capture_output=True, text=True)
         assert r.returncode == 0, (p, r.stdout, r.stderr)
+
+
+def test_conv_weight_cin3_packing(pkg):
+    """SVR2_WL_CIN3 (include/seedvr2_hip.h): k = (kt*3 + ky)*12 + kx*4 + c, pad channel and k >= 108 zero."""
+    hip = pkg.hip
+    w = torch.randn(128, 3, 3, 3, 3)
+    p = hip.conv_weight_cin3(w)
+    assert p.shape == (128, 128) and p.dtype == torch.bfloat16
+    wb = w.to(torch.bfloat16)
+    for (n, c, kt, ky, kx) in [(0, 0, 0, 0, 0), (5, 2, 1, 2, 0), (127, 1, 2, 2, 2), (64, 0, 2, 0, 1)]:
+        assert p[n, (kt * 3 + ky) * 12 + kx * 4 + c] == wb[n, c, kt, ky, kx]
+    assert (p[:, 108:] == 0).all() and (p[:, 3:108:4] == 0).all()
+    with pytest.raises(hip.HipError):
+        hip.conv_weight_cin3(torch.randn(64, 3, 3, 3, 3))

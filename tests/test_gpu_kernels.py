@@ -270,6 +270,47 @@ def test_conv3d_split_k(pkg, gpu, case, lib_option):
     assert pa.shape == pb.shape and torch.allclose(pa, pb, rtol=2e-3, atol=2e-2)
 
 
+CIN3_CASES = [
+    # T, H, W, with_carry
+    (1, 16, 32, False),        # exactly one patch
+    (3, 37, 50, True),         # ragged on both edges, carried head
+    (2, 7, 5, False),          # image smaller than a patch, replicated head
+    (5, 48, 96, True),         # several patches per frame, more patches than ... frames in flight
+    (4, 130, 70, False),
+]
+
+
+@pytest.mark.parametrize("case", CIN3_CASES)
+def test_conv_in_fused_cin3(pkg, gpu, case):
+    """conv_in.hip (Cin = 3 -> 128, halo in LDS, operands gathered from it, W in registers): against the fp32 conv of the
+    same bf16 inputs, against the im2col + GEMM path it replaces, and its GroupNorm partial sums against the sums of its
+    own rounded outputs.  [ref: causal_inflation_lib.py:250-305 through Encoder3D.conv_in]"""
+    hip = pkg.hip
+    T, H, W, with_carry = case
+    k, s, npad, pad_hw, Cout = (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1), 128
+    x = rnd(T, H, W, 3, seed=40)
+    w = rnd(Cout, *k, 3, seed=41, scale=0.2)                       # [Cout, kt, kh, kw, Cin]
+    b = rnd(Cout, seed=42)
+    carry = rnd(npad, H, W, 3, seed=43) if with_carry else None
+    ref = conv_ref(x, w, b, k, s, npad, pad_hw, carry)
+    xd, cd = dev_bf16(x, gpu), None if carry is None else dev_bf16(carry, gpu)
+    w5 = w.permute(0, 4, 1, 2, 3).contiguous().to(gpu)            # reference layout [Cout, Cin, kt, kh, kw]
+    out, part = hip.conv3d(xd, hip.conv_weight_cin3(w5), Cout, k, s, npad=npad, pad_hw=pad_hw, carry=cd, bias=b.to(gpu),
+                           w_layout=hip.WL_CIN3, gn_stats=True)
+    assert_close(out, ref, f"conv_in fused {case}")
+    # the path it replaces: same products, fp32 sums in another order -> at most one bf16 ulp apart, rarely
+    col = hip.im2col3d(xd, k, s, npad=npad, pad_hw=pad_hw, carry=cd, kpad=128)
+    old = hip.gemm(col, hip.pad_weight(w.reshape(Cout, -1).to(gpu), 128), Cout, bias=b.to(gpu)).view(T, H, W, Cout)
+    diff = (out.float() - old.float()).abs()
+    assert (diff > 0).float().mean() < 0.02, (diff > 0).float().mean()
+    assert (diff <= out.float().abs() * 2 ** -7 + 1e-6).all()
+    # GroupNorm partials: per frame and channel, (sum, sum of squares) of the rounded outputs, folded over the patches
+    o = out.float()
+    got = part.buf.sum(dim=1)                                       # [T, 2, C]
+    assert torch.allclose(got[:, 0], o.sum(dim=(1, 2)), rtol=1e-3, atol=1e-2 * math.sqrt(H * W))
+    assert torch.allclose(got[:, 1], (o * o).sum(dim=(1, 2)), rtol=1e-3, atol=1e-2)
+
+
 @pytest.mark.parametrize("Cin,with_carry", [(3, False), (16, True)])
 def test_im2col_gemm_small_cin(pkg, gpu, Cin, with_carry):
     hip = pkg.hip
