@@ -272,6 +272,10 @@ class Runtime:
             vcfg.decode_split = int(os.environ["SVR2_DECODE_SPLIT"])
         if os.environ.get("SVR2_ENCODE_SPLIT"):
             vcfg.encode_split = int(os.environ["SVR2_ENCODE_SPLIT"])
+        if os.environ.get("SVR2_ENCODE_FIRST"):
+            vcfg.encode_first = int(os.environ["SVR2_ENCODE_FIRST"])
+        if os.environ.get("SVR2_DECODE_FIRST"):
+            vcfg.decode_first = int(os.environ["SVR2_DECODE_FIRST"])
         vsd = pkg.vae.synthetic_state_dict(vcfg, dev, seed=1)
         vae = pkg.vae.VideoVAEHip(vcfg, vsd, dev)
         dcfg = pkg.dit.CFG_7B if model == "7b" else pkg.dit.CFG_3B
