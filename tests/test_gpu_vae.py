@@ -60,6 +60,32 @@ def test_conv_epilogue_groupnorm_statistics_and_carry(pkg, gpu, T, H, W, Cin, Co
     assert torch.equal(carry, fused[T - 2:])
 
 
+@pytest.mark.parametrize("C,tiles", [(128, 2500), (256, 1024 + 7), (512, 4096), (128, 300), (64, 2048)])
+def test_groupnorm_finalize_folds_many_tiles(pkg, gpu, C, tiles):
+    """svr2_groupnorm_finalize over thousands of per-tile partials (a 4K frame has 16 200): the unrolled fold (four tiles'
+    loads in flight, channels-per-group 4 / 8 / 16) and its remainder loop against an fp64 fold of the same partials on
+    the host; C = 64 (two channels per group) takes the plain loop.  [ref: causal_inflation_lib.py:354-409 GroupNorm]"""
+    hip = pkg.hip
+    Fr, H, W, G, eps = 2, 16, 24, 32, 1e-6
+    g = torch.Generator().manual_seed(77)
+    buf = torch.empty(Fr, tiles, 2, C)
+    buf[:, :, 0] = 0.05 * torch.randn(Fr, tiles, C, generator=g)
+    buf[:, :, 1] = 1.0 + torch.rand(Fr, tiles, C, generator=g)
+    x = rnd(Fr, H, W, C, seed=78)
+    gamma, beta = rnd(C, seed=79) * 0.1 + 1, rnd(C, seed=80) * 0.1
+    part = hip.GnPartial(buf.to(gpu), tiles)
+    got = hip.groupnorm_silu(dev_bf16(x, gpu), gamma.to(gpu), beta.to(gpu), G, eps, silu=False, partial=part).float().cpu()
+    n = float(H * W * (C // G))
+    sums = buf.double().sum(dim=1).reshape(Fr, 2, G, C // G).sum(dim=3)          # [F, 2, G]
+    mean = sums[:, 0] / n
+    var = (sums[:, 1] / n - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    a = (rstd.float().repeat_interleave(C // G, dim=1) * gamma)                    # [F, C]
+    bsh = beta - mean.float().repeat_interleave(C // G, dim=1) * a
+    want = x * a[:, None, None, :] + bsh[:, None, None, :]
+    assert_close(got, want, f"groupnorm finalize C={C} tiles={tiles}")
+
+
 @pytest.mark.parametrize("frames,P", [(2, 200), (1, 4096), (3, 129)])
 def test_attn_d512(pkg, gpu, frames, P):
     qkv = rnd(frames * P, 1536, seed=4)
