@@ -328,7 +328,11 @@ int launch(const KArgs& a, hipStream_t s) {
         ((a.K >= 1024 && tiles1 > 512 && !a.a_rows) || (ver == 3 && a.K >= 128))) {
         if (svr2::opt(svr2::OPT_GEMM4, 1) != 0) return gemm4_launch(EPI, a, s);
     }
-    const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.cg.Cin <= 128 && a.N == 128);
+    // (N = 128 with more than 128 input channels: slower on the 3x3 convs, see above - but the 1x1x1 shortcut 256 -> 128 at
+    //  full resolution is HBM-bound with a four-step K loop, where the 3-deep ring of the 256-row geometry streams at
+    //  5.0 TB/s against 2.6: 9.7 -> 5.1 ms on four 4K frames, tools/kernel_bench.py shortcut4k)
+    const bool pointwise = AMODE == A_CONV && a.cg.kt * a.cg.kh * a.cg.kw == 1;
+    const bool v2_shape = (a.N % 256 == 0) || (AMODE == A_CONV && a.N == 128 && (a.cg.Cin <= 128 || pointwise));
     if (((ver == 2 && tiles2 >= 384 && v2_shape) || ver == 3) && a.K % 32 == 0)
         return gemm2_launch(AMODE, EPI, a, s);  // ver 3: always (tests)
     const bool big = g_force_bm() == 256;

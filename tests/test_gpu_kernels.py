@@ -175,6 +175,26 @@ def test_conv3d(pkg, gpu, case):
     assert_close(out, ref, f"conv3d {case}")
 
 
+def test_conv3d_pointwise_shortcut_on_a_wide_grid(pkg, gpu, lib_option):
+    """The 1x1x1 shortcut 256 -> 128 of the decoder's last up block on enough pixels for the 256-row streaming geometry
+    (gemm2, >= 384 tiles: where a 4K frame runs it): against the fp32 conv and against the 128-row kernel (SVR2_GEMM_V=1).
+    [ref: attn_video_vae.py ResnetBlock3D.conv_shortcut through causal_inflation_lib.py:84-113]"""
+    hip = pkg.hip
+    T, H, W, Cin, Cout = 2, 224, 225, 256, 128
+    x = rnd(T, H, W, Cin, seed=60)
+    w = rnd(Cout, 1, 1, 1, Cin, seed=61, scale=1 / 16)
+    b = rnd(Cout, seed=62)
+    ref = conv_ref(x, w, b, (1, 1, 1), (1, 1, 1), 0, (0, 0, 0, 0), None)
+    wd = hip.pad_weight(hip.conv_weight(w.permute(0, 4, 1, 2, 3)).to(gpu))
+    run = lambda: hip.conv3d(dev_bf16(x, gpu), wd, Cout, (1, 1, 1), npad=0, pad_hw=(0, 0, 0, 0), bias=b.to(gpu))
+    out = run()
+    assert_close(out, ref, "pointwise conv 256->128, wide grid")
+    lib_option("SVR2_GEMM_V", 1)
+    old = run()
+    diff = (out.float() - old.float()).abs()
+    assert (diff > 0).float().mean() < 0.02 and (diff <= out.float().abs() * 2 ** -7 + 1e-6).all()
+
+
 HALO_CASES = [
     # T, H, W, Cin, Cout, kt, with_carry, resid
     (2, 16, 16, 64, 256, 3, False, False),

@@ -237,6 +237,29 @@ if __name__ == "__main__":
                 print(f"conv {H}x{W} {Cin}->{Cout}: hot {th*1e6:.1f} us ({fl/th/1e12:.0f} TFLOP/s)  cold {tc*1e6:.1f} us "
                       f"({fl/tc/1e12:.0f} TFLOP/s)  x{tc/th:.2f}", flush=True)
             del ws
+    if "shortcut4k" in which:   # the decoder's 1x1x1 shortcut conv 256 -> 128 on four 4K frames (HBM-bound: 17 GB in, 8.5 out)
+        T, H, W, Cin, Cout = 4, 2160, 3840, 256, 128
+        x = rb(T, H, W, Cin)
+        w5 = rb(Cout, Cin, 1, 1, 1, scale=1 / 16)
+        wr = hip.pad_weight(hip.conv_weight(w5))
+        b = torch.zeros(Cout, device=dev)
+        out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        nbytes = x.numel() * 2 + out.numel() * 2
+        def conv():
+            hip.conv3d(x, wr, Cout, (1, 1, 1), npad=0, pad_hw=(0, 0, 0, 0), bias=b, out=out)
+        def dense():
+            hip.gemm(x.view(-1, Cin), wr, Cout, out.view(-1, Cout), bias=b)
+        for name, fn, opts in (("conv path", conv, {}), ("conv path, BM=256", conv, {"SVR2_GEMM_BM": 256}),
+                               ("conv path, gemm2", conv, {"SVR2_GEMM_V": 3}), ("dense gemm", dense, {}),
+                               ("dense gemm, BM=256", dense, {"SVR2_GEMM_BM": 256}),
+                               ("dense gemm, gemm2 256x128", dense, {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0}),
+                               ("torch.matmul", lambda: torch.matmul(x.view(-1, Cin), w5.view(Cout, Cin).t()), {})):
+            for k, v in opts.items():
+                hip.set_option(k, v)
+            t = timeit(fn, iters=5, warm=2)
+            for k in opts:
+                hip.set_option(k, None)
+            print(f"shortcut 4x4K 256->128 [{name}]: {t*1e3:.2f} ms  {nbytes/t/1e12:.2f} TB/s", flush=True)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
