@@ -250,17 +250,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
             for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + (a.gate ? a.gate[n + e] : 1.f) * v[e];
             dst = (long long)m * a.ldc + n;
         } else if (EPI == SVR2_EPI_PIXSHUF3D) {
-            const int Cc = a.ps_c, tz = a.ps_tz;
-            const int qd = n / Cc, ch = n - qd * Cc;
-            const int z = qd % tz, yy = (qd / tz) & 1, xx = qd / (2 * tz);
-            const int w = m % a.ps_w, t2 = m / a.ps_w;
-            const int h = t2 % a.ps_h, f = t2 / a.ps_h;
-            int fo = f * tz + z;
-            if (a.ps_drop) {
-                if (fo == 1) continue;
-                if (fo > 1) fo -= 1;
-            }
-            dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
+            if (!pixshuf_dst(a, m, n, dst)) continue;
         } else if (EPI == SVR2_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {  // nn.GELU("tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -459,6 +449,8 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
         case SVR2_EPI_PIXSHUF3D: {
             a.ps_frames = d->ps_frames; a.ps_h = d->ps_h; a.ps_w = d->ps_w; a.ps_c = d->ps_c; a.ps_tz = d->ps_tz;
             a.ps_drop = d->ps_drop_head;
+            a.ps_wd = make_fastdiv((uint32_t)d->ps_w); a.ps_hd = make_fastdiv((uint32_t)d->ps_h);
+            a.ps_cd = make_fastdiv((uint32_t)d->ps_c);
             SVR2_CHECK(d->ps_c > 0 && d->ps_c % 8 == 0 && (d->ps_tz == 1 || d->ps_tz == 2) &&
                            d->N == (int64_t)d->ps_c * 4 * d->ps_tz &&
                            d->M == (int64_t)d->ps_frames * d->ps_h * d->ps_w,

@@ -12,6 +12,26 @@ struct ConvGeom {
     int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
 };
 
+// Division by a launch constant without the ~40-instruction integer divide (Granlund-Montgomery, round-up form, exact
+// for every 32-bit numerator): the pixel-shuffle epilogue splits every output row index three ways per 16-byte store.
+struct FastDiv {
+    uint32_t mul, sh, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{0, 0, d};
+    if (d <= 1) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.sh = l;
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    if (f.d <= 1) return n;
+    const uint32_t t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> 1)) >> (f.sh - 1);
+}
+
 struct KArgs {
     const bf16* A;
     const bf16* W;
@@ -29,6 +49,7 @@ struct KArgs {
     long long lda, ldc, ldr;
     int M, N, K, nbm, nbn;
     int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
+    FastDiv ps_wd, ps_hd, ps_cd;   // divisors ps_w, ps_h, ps_c
     ConvGeom cg;
 };
 
@@ -63,6 +84,25 @@ __device__ __forceinline__ int tile_row_to_m(const KArgs& a, int tm, int row) {
         return (t * a.cg.Ho + y) * a.cg.Wo + x;
     }
     return tm * BM + row;
+}
+
+
+// SVR2_EPI_PIXSHUF3D: element offset of GEMM output (row m = input pixel, column n = (xx, yy, z, channel)) in the
+// pixel-shuffled tensor [F*tz (-1), 2H, 2W, C]; false = the dropped head frame  [ref: attn_video_vae.py:140-153]
+__device__ __forceinline__ bool pixshuf_dst(const KArgs& a, int m, int n, long long& dst) {
+    const int Cc = a.ps_c;
+    const int qd = (int)fdiv((uint32_t)n, a.ps_cd), ch = n - qd * Cc;
+    const int q2 = a.ps_tz == 2 ? qd >> 1 : qd, z = a.ps_tz == 2 ? qd & 1 : 0;     // qd / tz, qd % tz
+    const int yy = q2 & 1, xx = q2 >> 1;
+    const int t2 = (int)fdiv((uint32_t)m, a.ps_wd), w = m - t2 * a.ps_w;
+    const int f = (int)fdiv((uint32_t)t2, a.ps_hd), h = t2 - f * a.ps_h;
+    int fo = f * a.ps_tz + z;
+    if (a.ps_drop) {
+        if (fo == 1) return false;
+        if (fo > 1) fo -= 1;
+    }
+    dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
+    return true;
 }
 
 // Fused epilogues on a finished bf16 tile in LDS (row pitch EPI_LD bytes, BM rows x BN columns, bias already added):
@@ -103,17 +143,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& a, const char* smem, 
             for (int e = 0; e < 8; ++e) v[e] = bf2f(rv[e]) + (a.gate ? a.gate[n + e] : 1.f) * v[e];
             dst = (long long)m * a.ldc + n;
         } else if (EPI == SVR2_EPI_PIXSHUF3D) {
-            const int Cc = a.ps_c, tz = a.ps_tz;
-            const int qd = n / Cc, ch = n - qd * Cc;
-            const int z = qd % tz, yy = (qd / tz) & 1, xx = qd / (2 * tz);
-            const int w = m % a.ps_w, t2 = m / a.ps_w;
-            const int h = t2 % a.ps_h, f = t2 / a.ps_h;
-            int fo = f * tz + z;
-            if (a.ps_drop) {
-                if (fo == 1) continue;
-                if (fo > 1) fo -= 1;
-            }
-            dst = (((long long)fo * (2 * a.ps_h) + (2 * h + xx)) * (2 * a.ps_w) + (2 * w + yy)) * Cc + ch;
+            if (!pixshuf_dst(a, m, n, dst)) continue;
         } else if (EPI == SVR2_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {

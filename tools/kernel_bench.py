@@ -260,6 +260,31 @@ if __name__ == "__main__":
             for k in opts:
                 hip.set_option(k, None)
             print(f"shortcut 4x4K 256->128 [{name}]: {t*1e3:.2f} ms  {nbytes/t/1e12:.2f} TB/s", flush=True)
+    if "pixshuf4k" in which:   # the last Upsample3D of the decoder: 1x1x1 conv 256 -> 1024 + pixel shuffle, 1080p -> 4K, 4 frames
+        T, H, W, Cc, N = 4, 1080, 1920, 256, 1024
+        x = rb(T, H, W, Cc)
+        w = hip.pad_weight(rb(N, Cc, scale=1 / 16))
+        b = torch.zeros(N, device=dev)
+        nbytes = x.numel() * 2 + T * H * W * N * 2
+        fn = lambda: hip.gemm(x.view(T * H * W, Cc), w, N, epilogue=hip.EPI_PIXSHUF3D, bias=b, pixshuf=(T, H, W, Cc, 1, False))
+        outp = torch.empty(T * H * W, N, dtype=torch.bfloat16, device=dev)
+        for name, opts in (("default", {}), ("gemm2 256x128", {"SVR2_GEMM2_NARROW": 1})):   # same GEMM, row-major stores
+            for k, v in opts.items():
+                hip.set_option(k, v)
+            t = timeit(lambda: hip.gemm(x.view(T * H * W, Cc), w, N, outp, bias=b), iters=5, warm=2)
+            for k in opts:
+                hip.set_option(k, None)
+            print(f"same GEMM with the plain bias epilogue [{name}]: {t*1e3:.2f} ms  {nbytes/t/1e12:.2f} TB/s", flush=True)
+        del outp
+        for name, opts in (("default (gemm2 256x256)", {}), ("gemm2 256x128", {"SVR2_GEMM2_NARROW": 1}),
+                           ("gemm 128x128 2-deep", {"SVR2_GEMM_V": 1}), ("gemm 256x128 3-deep", {"SVR2_GEMM_V": 1, "SVR2_GEMM_BM": 256})):
+            for k, v in opts.items():
+                hip.set_option(k, v)
+            t = timeit(fn, iters=5, warm=2)
+            for k in opts:
+                hip.set_option(k, None)
+            print(f"pixel-shuffle GEMM 4x1080p 256->1024 [{name}]: {t*1e3:.2f} ms  {nbytes/t/1e12:.2f} TB/s  "
+                  f"{2*T*H*W*Cc*N/t/1e12:.0f} TFLOP/s", flush=True)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
