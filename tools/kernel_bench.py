@@ -285,6 +285,18 @@ if __name__ == "__main__":
                 hip.set_option(k, None)
             print(f"pixel-shuffle GEMM 4x1080p 256->1024 [{name}]: {t*1e3:.2f} ms  {nbytes/t/1e12:.2f} TB/s  "
                   f"{2*T*H*W*Cc*N/t/1e12:.0f} TFLOP/s", flush=True)
+    if "gnapply" in which:   # GroupNorm apply + SiLU alone (statistics given as partials): 4 frames of 4K, 128 channels
+        Fr, H, W, Cc = 4, 2160, 3840, 128
+        x = rb(Fr, H, W, Cc)
+        g, b = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+        out = torch.empty_like(x)
+        buf = torch.zeros(Fr, 64, 2, Cc, device=dev); buf[:, :, 1] = H * W / 64.0
+        part = hip.GnPartial(buf, 64)
+        t = timeit(lambda: hip.groupnorm_silu(x, g, b, 32, 1e-6, out=out, partial=part), iters=10, warm=3)
+        print(f"gn finalize+apply {tuple(x.shape)} var={os.environ.get('SVR2_GNAPPLY_VAR','0')}: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
+        y2 = torch.empty_like(x)
+        t = timeit(lambda: y2.copy_(x), iters=10, warm=3)
+        print(f"torch copy of the same tensor: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
