@@ -293,7 +293,7 @@ if __name__ == "__main__":
         buf = torch.zeros(Fr, 64, 2, Cc, device=dev); buf[:, :, 1] = H * W / 64.0
         part = hip.GnPartial(buf, 64)
         t = timeit(lambda: hip.groupnorm_silu(x, g, b, 32, 1e-6, out=out, partial=part), iters=10, warm=3)
-        print(f"gn finalize+apply {tuple(x.shape)} var={os.environ.get('SVR2_GNAPPLY_VAR','0')}: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
+        print(f"gn finalize+apply {tuple(x.shape)}: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
         y2 = torch.empty_like(x)
         t = timeit(lambda: y2.copy_(x), iters=10, warm=3)
         print(f"torch copy of the same tensor: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
