@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const KArgs a) {
         const int it = t + tap_t;                  // stride 1 in time
         const bool head = it < a.cg.npad;
         const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
-        const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+        const int fidx = head ? (a.cg.carry ? max(it - a.cg.crep, 0) : 0) : it - a.cg.npad;
         return base + fidx * frame_bytes + org + cs * (BK * 2);
     };
     auto issue_halo = [&](int u0, int u1, const char* sb, char* hbuf) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_wr_kernel(const KArgs a) {
         const int it = t + tap_t;
         const bool head = it < a.cg.npad;
         const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
-        const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+        const int fidx = head ? (a.cg.carry ? max(it - a.cg.crep, 0) : 0) : it - a.cg.npad;
         return base + fidx * frame_bytes + org + cs * (BK * 2);
     };
     auto issue_halo = [&](const char* sb, char* hbuf) {      // waves 4-7: pieces q = u*4 + (wave - 4)

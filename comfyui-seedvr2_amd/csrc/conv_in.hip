@@ -37,7 +37,7 @@ struct CinArgs {
     const float* bias;
     bf16* y;
     float* stats;
-    int T, H, W, npad, tiles_x, tiles_y;
+    int T, H, W, npad, crep, tiles_x, tiles_y;
     long long total;
 };
 
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void conv_in3_kernel(const CinArgs a) {
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const int p = t + kt;                                    // padded frame index
             const bf16* src;
-            if (p < a.npad) src = a.carry ? a.carry + (long long)p * frame_px * 3 : a.x;    // head: carried frames or frame 0
+            if (p < a.npad)                                          // head: carried frames (the first one also stands
+                src = a.carry ? a.carry + (long long)max(p - a.crep, 0) * frame_px * 3 : a.x;   // for missing ones) or frame 0
             else src = a.x + (long long)(p - a.npad) * frame_px * 3;
             bf16x4 v = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
@@ -196,6 +197,7 @@ int conv_in3_launch(const svr2_conv3d_desc* d, hipStream_t s) {
     a.x = (const bf16*)d->x; a.carry = (const bf16*)d->carry; a.w = (const bf16*)d->w; a.bias = d->bias;
     a.y = (bf16*)d->y; a.stats = d->gn_partial;
     a.T = d->T; a.H = d->Hi; a.W = d->Wi; a.npad = d->npad;
+    a.crep = (d->carry && d->carry_frames > 0) ? d->npad - d->carry_frames : 0;
     a.tiles_x = (d->Wo + TW - 1) / TW; a.tiles_y = (d->Ho + TH - 1) / TH;
     a.total = (long long)d->To * a.tiles_x * a.tiles_y;
     const long long grid = a.total < 512 ? a.total : 512;     // persistent: two workgroups per CU of a 256-CU part

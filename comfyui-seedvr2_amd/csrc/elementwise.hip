@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void patch_out_x0_kernel(const bf16* __restric
 struct Im2colArgs {
     const bf16* x; const bf16* carry; bf16* col;
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
+    int crep;       // head frames the carry does not hold (svr2_conv3d_desc.carry_frames): they read carry[0]
     long long kpad;
 };
 // One thread = 8 consecutive K columns of one output pixel (one 16-byte store; a row of the col matrix is written
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const Im2colArgs a) {
             if (kcol < Kreal) {
                 const int iy = iy0 + ky, ix = ix0 + kx, it = it0 + kt;
                 if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
-                    const bf16* fb = it < a.npad ? (a.carry ? a.carry + (long long)it * frame : a.x)
+                    const bf16* fb = it < a.npad ? (a.carry ? a.carry + (long long)max(it - a.crep, 0) * frame : a.x)
                                                  : a.x + (long long)(it - a.npad) * frame;
                     v = bf2f(fb[((long long)iy * a.Wi + ix) * a.Cin + c]);
                 }
@@ -377,6 +378,8 @@ extern "C" int svr2_im2col3d(const svr2_conv3d_desc* d, void* col, int64_t kpad,
     a.T = d->T; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
     a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.npad = d->npad; a.pad_h0 = d->pad_h0; a.pad_w0 = d->pad_w0;
     a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.kpad = kpad;
+    SVR2_CHECK(d->carry_frames >= 0 && d->carry_frames <= d->npad, SVR2_E_SHAPE, "svr2_im2col3d: carry_frames outside [0, npad]");
+    a.crep = (d->carry && d->carry_frames > 0) ? d->npad - d->carry_frames : 0;
     const long long total = (long long)d->To * d->Ho * d->Wo * (kpad / 8);
     hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
     SVR2_LAUNCH_CHECK();

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const KArgs a) {
             const int it = ct[i] + tap_t;
             const bool head = it < a.cg.npad;
             const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
-            const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+            const int fidx = head ? (a.cg.carry ? max(it - a.cg.crep, 0) : 0) : it - a.cg.npad;
             a_ptr[i] = base + fidx * frame_bytes + rowoff[i];
         }
     };
@@ -480,6 +480,7 @@ static void conv_kargs(const svr2_conv3d_desc* d, KArgs& a) {
     a.ldc = d->Cout; a.ldr = d->Cout;
     a.M = (int)((long long)d->To * d->Ho * d->Wo); a.N = d->Cout; a.K = d->kt * d->kh * d->kw * d->Cin;
     a.cg.carry = (const bf16*)d->carry;
+    a.cg.crep = (d->carry && d->carry_frames > 0) ? d->npad - d->carry_frames : 0;
     a.cg.T = d->T; a.cg.Hi = d->Hi; a.cg.Wi = d->Wi; a.cg.Cin = d->Cin;
     a.cg.kt = d->kt; a.cg.kh = d->kh; a.cg.kw = d->kw; a.cg.st = d->st; a.cg.sh = d->sh; a.cg.sw = d->sw;
     a.cg.npad = d->npad; a.cg.pad_h0 = d->pad_h0; a.cg.pad_w0 = d->pad_w0;
@@ -502,6 +503,8 @@ extern "C" int64_t svr2_conv3d_split_ws_bytes(const svr2_conv3d_desc* d) {
 
 extern "C" int svr2_conv3d(const svr2_conv3d_desc* d, void* stream) {
     SVR2_CHECK(d && d->x && d->w && d->y && d->zero_page, SVR2_E_ARG, "svr2_conv3d: null pointer");
+    SVR2_CHECK(d->carry_frames >= 0 && d->carry_frames <= d->npad, SVR2_E_SHAPE,
+               "svr2_conv3d: carry_frames=%d outside [0, npad=%d]", d->carry_frames, d->npad);
     if (d->w_layout == SVR2_WL_CIN3) {   // fused conv_in (conv_in.hip)
         SVR2_CHECK(d->Cin == 3 && d->Cout == 128 && d->kt == 3 && conv_halo_shape(d) && d->npad == 2 && d->To == d->T &&
                        d->T >= 1 && d->Hi >= 1 && d->Wi >= 1,

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(Geo2<BN>::NT, 2) void gemm2_kernel(const KArgs a) {
             const int it = ct[i] + tap_t;
             const bool head = it < a.cg.npad;
             const char* base = (head && a.cg.carry) ? (const char*)a.cg.carry : (const char*)a.A;
-            const int fidx = head ? (a.cg.carry ? it : 0) : it - a.cg.npad;
+            const int fidx = head ? (a.cg.carry ? max(it - a.cg.crep, 0) : 0) : it - a.cg.npad;
             a_ptr[i] = base + fidx * frame_bytes + rowoff[i];
         }
     };

@@ -9,6 +9,7 @@ enum AMode { A_DENSE = 0, A_CONV = 1 };
 struct ConvGeom {
     const bf16* carry;
     int T, Hi, Wi, Cin, kt, kh, kw, st, sh, sw, npad, pad_h0, pad_w0, To, Ho, Wo;
+    int crep;                      // head frames the carry does not hold (npad - carry_frames): they read carry[0]
     int patch, tiles_x, tiles_y;   // patch != 0: an M-tile is a (BM/16) x 16 pixel patch of one frame
 };
 

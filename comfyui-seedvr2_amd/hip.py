@@ -51,6 +51,7 @@ class Conv3dDesc(C.Structure):
         ("gn_partial", C.c_void_p),
         ("split_ws", C.c_void_p),
         ("split_ws_bytes", C.c_int64),
+        ("carry_frames", C.c_int32),
     ]
 
 
@@ -326,6 +327,7 @@ def _conv_desc(x, w, cout, k, s, npad, pad_hw, carry, bias, resid, y, w_layout=W
     d.zero_page = zero_page(x.device).data_ptr()
     d.w_layout = w_layout
     d.gn_partial = gn_partial.data_ptr() if gn_partial is not None else None
+    d.carry_frames = carry.shape[0] if carry is not None else 0
     return d, (To, Ho, Wo)
 
 
@@ -348,8 +350,9 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, cout: int, k, s=(1, 1, 1), *, npad:
         raise HipError(f"conv3d: weight shape {tuple(w.shape)} does not match k={k} Cin={Cin} cout={cout}")
     if carry is not None:
         _bf16c(carry, "conv3d.carry")
-        if tuple(carry.shape) != (npad, Hi, Wi, Cin) or not carry.is_contiguous():
-            raise HipError(f"conv3d: carry must be [{npad},{Hi},{Wi},{Cin}], got {tuple(carry.shape)}")
+        if tuple(carry.shape[1:]) != (Hi, Wi, Cin) or not (1 <= carry.shape[0] <= npad) or not carry.is_contiguous():
+            raise HipError(f"conv3d: carry must be [1..{npad},{Hi},{Wi},{Cin}] (fewer frames than npad: the first one also "
+                           f"stands for the missing earlier ones), got {tuple(carry.shape)}")
     To, Ho, Wo = conv_out_size(T, Hi, Wi, k, s, npad, pad_hw)
     if To < 1 or Ho < 1 or Wo < 1:
         raise HipError("conv3d: empty output")
@@ -385,7 +388,8 @@ def im2col3d(x: torch.Tensor, k, s, *, npad: int, pad_hw, carry: Optional[torch.
     _bf16c(x, "im2col3d.x")
     if x.dim() != 4 or not x.is_contiguous():
         raise HipError("im2col3d: x must be contiguous [T,H,W,C]")
-    if carry is not None and (tuple(carry.shape) != (npad,) + tuple(x.shape[1:]) or not carry.is_contiguous()):
+    if carry is not None and (tuple(carry.shape[1:]) != tuple(x.shape[1:]) or not (1 <= carry.shape[0] <= npad)
+                              or not carry.is_contiguous()):
         raise HipError("im2col3d: bad carry shape")
     d, (To, Ho, Wo) = _conv_desc(x, x, 8, k, s, npad, pad_hw, carry, None, None, None)
     col = torch.empty(To * Ho * Wo, kpad, dtype=torch.bfloat16, device=x.device)

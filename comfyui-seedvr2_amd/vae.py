@@ -159,7 +159,11 @@ class VideoVAEHip:
                 st.mem[name] = None
                 st.mem[name] = x[x.shape[0] - keep:]
             elif not st.active and x.shape[0] == 1:
-                st.mem[name] = x.expand(keep, -1, -1, -1).contiguous()   # first chunk of one frame: replicas of it
+                # first chunk of one frame: the state is [f0, f0].  The kernels take the single frame as the carry and let
+                # it stand for the missing earlier one (svr2_conv3d_desc.carry_frames), so this is a view too - the two
+                # replicas were two 2.1 GB copies per full-resolution conv of a 4K batch (0.4 % of the step)
+                st.mem[name] = None
+                st.mem[name] = x
             else:
                 head = st.mem.get(name) if st.active else None
                 head = head if head is not None else x[:1].expand(npad, -1, -1, -1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SVR2_ABI_VERSION 1
+#define SVR2_ABI_VERSION 2
 
 enum {
     SVR2_OK = 0,
@@ -141,6 +141,11 @@ typedef struct svr2_conv3d_desc {
                                  512-channel convs of a small image: 16-128 tiles, 48 channel slices) is split 2-8 ways along
                                  K; a second launch adds the fp32 partial tiles in a fixed order and finishes them.  NULL or
                                  too small: never split.  Split and unsplit results differ by fp32 summation order only. */
+    int32_t carry_frames;     /* frames in `carry`: 0 or npad = all npad head frames are given; 1 <= carry_frames < npad =
+                                 carry holds only the LAST carry_frames of the head and its first frame also stands for the
+                                 missing earlier ones - the state after a first chunk shorter than the head (one frame:
+                                 the reference's memory is then [f0, f0], causal_inflation_lib.py:266-278, 422-437), passed
+                                 as a view instead of a materialised copy */
 } svr2_conv3d_desc;
 
 int svr2_conv3d(const svr2_conv3d_desc* d, void* stream);

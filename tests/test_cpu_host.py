@@ -163,7 +163,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(pkg.hip.EXPORTS) == declared
     lib.svr2_abi_version.restype = ctypes.c_int
-    assert lib.svr2_abi_version() == 1
+    assert lib.svr2_abi_version() == 2
 
 
 def test_argument_validation_without_gpu(pkg):

@@ -290,6 +290,37 @@ def test_conv3d_split_k(pkg, gpu, case, lib_option):
     assert pa.shape == pb.shape and torch.allclose(pa, pb, rtol=2e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("path", ["tap_staged", "tap_staged_wide", "halo", "halo_lds_w", "cin3", "im2col"])
+def test_conv3d_short_carry_equals_materialised_replicas(pkg, gpu, path, lib_option):
+    """svr2_conv3d_desc.carry_frames: a carry of ONE frame with npad = 2 (the state after a one-frame first chunk) must give
+    the same bits as the materialised [f, f] the reference keeps [ref: causal_inflation_lib.py:266-278, 422-437] - on
+    every kernel that reads a carry."""
+    hip = pkg.hip
+    k, s, npad, pad_hw = (3, 3, 3), (1, 1, 1), 2, (1, 1, 1, 1)
+    Cin, Cout = (3, 128) if path in ("cin3", "im2col") else (64, 128)
+    T, H, W = (3, 128, 260) if path == "tap_staged_wide" else (3, 20, 37)     # wide: >= 384 tiles of 256 rows -> gemm2
+    x, c1 = dev_bf16(rnd(T, H, W, Cin, seed=70), gpu), dev_bf16(rnd(1, H, W, Cin, seed=71), gpu)
+    c2 = c1.expand(2, -1, -1, -1).contiguous()
+    w5 = rnd(Cout, Cin, *k, seed=72, scale=0.1).to(gpu)
+    b = rnd(Cout, seed=73).to(gpu)
+    if path == "im2col":
+        run = lambda c: hip.im2col3d(x, k, s, npad=npad, pad_hw=pad_hw, carry=c, kpad=128)
+    elif path == "cin3":
+        run = lambda c: hip.conv3d(x, hip.conv_weight_cin3(w5), Cout, k, s, npad=npad, pad_hw=pad_hw, carry=c, bias=b,
+                                   w_layout=hip.WL_CIN3)
+    elif path.startswith("halo"):
+        if path == "halo_lds_w":
+            lib_option("SVR2_HALO_WR", 0)
+        run = lambda c: hip.conv3d(x, hip.conv_weight_tiled(w5), Cout, k, s, npad=npad, pad_hw=pad_hw, carry=c, bias=b,
+                                   w_layout=hip.WL_TILED_128x32)
+    else:
+        run = lambda c: hip.conv3d(x, hip.pad_weight(hip.conv_weight(w5)), Cout, k, s, npad=npad, pad_hw=pad_hw, carry=c,
+                                   bias=b)
+    full, short = run(c2), run(c1)
+    assert torch.equal(full, short)
+    assert not torch.equal(full, run(None))        # the carry is read at all (frame 0 of x differs from it)
+
+
 CIN3_CASES = [
     # T, H, W, with_carry
     (1, 16, 32, False),        # exactly one patch

@@ -297,6 +297,13 @@ if __name__ == "__main__":
         y2 = torch.empty_like(x)
         t = timeit(lambda: y2.copy_(x), iters=10, warm=3)
         print(f"torch copy of the same tensor: {t*1e3:.3f} ms  {2*x.numel()*2/t/1e12:.2f} TB/s", flush=True)
+    if "gemmsquare" in which:   # square bf16 GEMMs on random data, for comparison with published MI355X templates
+        for n in (4096, 8192):
+            for r in range(2):
+                bench_gemm(n, n, n)
+            a_, b_ = rb(n, n), rb(n, n)
+            t = timeit(lambda: torch.matmul(a_, b_.t()), iters=10, warm=3)
+            print(f"torch.matmul {n}^3: {t*1e3:.3f} ms  {2*n**3/t/1e12:.0f} TFLOP/s", flush=True)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
