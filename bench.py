@@ -276,6 +276,8 @@ class Runtime:
             vcfg.encode_first = int(os.environ["SVR2_ENCODE_FIRST"])
         if os.environ.get("SVR2_DECODE_FIRST"):
             vcfg.decode_first = int(os.environ["SVR2_DECODE_FIRST"])
+        if os.environ.get("SVR2_NORM_CARRY_COPY"):
+            vcfg.norm_carry_copy = os.environ["SVR2_NORM_CARRY_COPY"] != "0"
         vsd = pkg.vae.synthetic_state_dict(vcfg, dev, seed=1)
         vae = pkg.vae.VideoVAEHip(vcfg, vsd, dev)
         dcfg = pkg.dit.CFG_7B if model == "7b" else pkg.dit.CFG_3B

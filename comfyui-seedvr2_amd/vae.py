@@ -46,6 +46,9 @@ class VAEConfig:
     decode_split: int = 1   # latent frames per slice after the first
     encode_first: int = 1   # input frames in the first slice (reference: 1 + encode_split)
     decode_first: int = 1   # latent frames in the first slice (reference: 1 + decode_split)
+    norm_carry_copy: bool = True   # a GroupNorm that feeds a causal conv also writes that conv's next-chunk state (a copy of
+    #                                its last frames); False: the state is a VIEW of the norm's output, which then stays
+    #                                allocated until the next chunk has used it (no extra writes, more memory)
 
 
 class _State:
@@ -68,7 +71,8 @@ class VideoVAEHip:
         self.cfg = cfg
         self.device = torch.device(device)
         dev = self.device
-        self.fused_conv_in = os.environ.get("SVR2_CONV_IN_FUSED", "1") != "0"      # A/B switch, resolved once
+        self.fused_conv_in = os.environ.get("SVR2_CONV_IN_FUSED", "1") != "0"      # A/B switches, resolved once
+        self.first_carry_view = os.environ.get("SVR2_FIRST_CARRY_VIEW", "1") != "0"
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.convs: Dict[str, dict] = {}
         self.norms: Dict[str, tuple] = {}
@@ -158,6 +162,8 @@ class VideoVAEHip:
                 # chunk tensor stays allocated until the next chunk has consumed the carry.
                 st.mem[name] = None
                 st.mem[name] = x[x.shape[0] - keep:]
+            elif not st.active and x.shape[0] == 1 and not self.first_carry_view:
+                st.mem[name] = x.expand(keep, -1, -1, -1).contiguous()   # first chunk of one frame: replicas of it (A/B)
             elif not st.active and x.shape[0] == 1:
                 # first chunk of one frame: the state is [f0, f0].  The kernels take the single frame as the carry and let
                 # it stand for the missing earlier one (svr2_conv3d_desc.carry_frames), so this is a view too - the two
@@ -182,7 +188,7 @@ class VideoVAEHip:
         part = st.stats[1] if (st.stats is not None and st.stats[0] is x) else None
         st.stats = None
         carry_out = None
-        if carry_for is not None and not st.last:
+        if carry_for is not None and not st.last and self.cfg.norm_carry_copy:
             keep = self.convs[carry_for]["k"][0] - 1
             if 0 < keep <= x.shape[0]:
                 carry_out = torch.empty((keep,) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=x.device)
