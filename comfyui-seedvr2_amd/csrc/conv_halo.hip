@@ -566,10 +566,20 @@ __global__ __launch_bounds__(512, 2) void conv_halo_finish_kernel(const KArgs a)
 
 // K splits of a W-through-registers conv: the latent-resolution 512-channel convs of a small image are 16-128 tiles for
 // 256 CUs with a K loop of 48 slices; splitting the slices S ways fills the chip.  Power of two, >= 6 slices per split.
+// Second case, grids a little over ONE tile per CU (the latent-resolution convs of a 1080p frame: 270 tiles): every CU
+// works through one tile and a handful of CUs through two; halves of tiles pack tighter - ceil(2 tiles / 256) / 2 = 1.5
+// up to 384 tiles - at the price of the finishing launch (about 7 slices' worth of time): 270 tiles 503 -> 439 us.
+// Past two tiles per CU the same arithmetic predicts a gain that does not come (540 tiles: 760 -> 783 us), 480 tiles
+// split in two lose (509 -> 605 us) and so do 120 tiles split four ways (157 -> 177 us)
+// (tools/kernel_bench.py convsplit, profiles/r03_conv_split_mid.log).
 static int conv_halo_split(long long tiles, int nsl) {
     if (!svr2::opt(svr2::OPT_CONV_SPLIT, 1)) return 0;
     int lg = 0;
     while ((tiles << lg) < 192 && lg < 3 && (nsl >> (lg + 1)) >= 6) ++lg;
+    if (lg == 0 && tiles > 256 && nsl >= 12) {
+        const long long c0 = (tiles + 255) / 256, c1 = (2 * tiles + 255) / 256;
+        if (c0 == 2 && c1 * nsl + 14 < 2 * c0 * nsl) lg = 1;
+    }
     return lg;
 }
 

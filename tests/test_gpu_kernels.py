@@ -251,6 +251,7 @@ def test_conv3d_halo_resident(pkg, gpu, case, wr, lib_option):
     (2, 40, 56, 256, 256, 3, True, True),      # ragged patches, carried head, residual: 24 tiles, 24 slices -> 4 splits
     (1, 72, 80, 128, 128, 3, False, False),    # <32,128> geometry, 12 slices -> 2 splits
     (1, 48, 48, 384, 256, 1, False, True),     # kt = 1 (12 slices)
+    (1, 135, 240, 256, 512, 3, True, True),    # 270 tiles: a little over one per CU -> halves pack tighter (2 splits)
 ])
 def test_conv3d_split_k(pkg, gpu, case, lib_option):
     """Split-K path of the halo conv (small grids): against torch, against the unsplit kernel (fp32 summation order is

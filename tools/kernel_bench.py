@@ -304,6 +304,20 @@ if __name__ == "__main__":
             a_, b_ = rb(n, n), rb(n, n)
             t = timeit(lambda: torch.matmul(a_, b_.t()), iters=10, warm=3)
             print(f"torch.matmul {n}^3: {t*1e3:.3f} ms  {2*n**3/t/1e12:.0f} TFLOP/s", flush=True)
+    if "convsplit" in which:   # latent-resolution 512-channel convs of one 1080p / 1440p frame: tiles between 192 and 1024
+        for (H, W) in ((135, 240), (135, 480), (90, 160), (180, 320), (68, 120), (200, 256)):
+            x = rb(1, H, W, 512)
+            w = hip.conv_weight_tiled(rb(512, 512, 3, 3, 3, scale=0.02))
+            b = torch.zeros(512, device=dev)
+            out = torch.empty(1, H, W, 512, dtype=torch.bfloat16, device=dev)
+            fl = 2 * H * W * 512 * 512 * 27
+            tiles = ((H + 15) // 16) * ((W + 15) // 16) * 2
+            for mode in (0, 1):
+                hip.set_option("SVR2_CONV_SPLIT", mode)
+                t = timeit(lambda: hip.conv3d(x, w, 512, (3, 3, 3), npad=2, pad_hw=(1, 1, 1, 1), bias=b, out=out,
+                                              w_layout=hip.WL_TILED_128x32, gn_stats=True), iters=20, warm=3)
+                print(f"conv {H}x{W} 512->512 ({tiles} tiles) SVR2_CONV_SPLIT={mode}: {t*1e6:.0f} us  {fl/t/1e12:.0f} TFLOP/s", flush=True)
+            hip.set_option("SVR2_CONV_SPLIT", None)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
