@@ -574,9 +574,12 @@ class ResizeTaps(tuple):
         return obj
 
 
+_TAPS_SYNC = os.environ.get("SVR2_TAPS_SYNC") == "1"       # A/B switch, resolved once at import
+
+
 def _taps_bounds(taps):
     b = getattr(taps, "bounds", None)
-    if b is None or os.environ.get("SVR2_TAPS_SYNC") == "1":   # plain tuple from an outside caller (or the A/B switch):
+    if b is None or _TAPS_SYNC:   # plain tuple from an outside caller (or the A/B switch):
         # reduce on the device -- this synchronises the host with the stream
         _, ymin, ycnt, _, xmin, xcnt = taps
         b = (int((ymin + ycnt).max()), int((xmin + xcnt).max()), int(ycnt.max()), int(xcnt.max()))
