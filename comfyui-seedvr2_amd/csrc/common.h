@@ -66,7 +66,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // Every switch is resolved ONCE: from svr2_set_option if it was called, else from the environment variable of the same
 // name at first use, else the built-in default.  No getenv on the launch path.
 namespace svr2 {
-enum Opt { OPT_HALO_WR, OPT_GEMM_V, OPT_GEMM4, OPT_GEMM_BM, OPT_GEMM2_NARROW, OPT_CONV_LINEAR_TILES, OPT_ATTN_V, OPT_CONV_TFAST, OPT_CONV_SPLIT, OPT_ATTN5_V, OPT_HALO_PREF, OPT_COUNT };
+enum Opt { OPT_HALO_WR, OPT_GEMM_V, OPT_GEMM4, OPT_GEMM_BM, OPT_GEMM2_NARROW, OPT_CONV_LINEAR_TILES, OPT_ATTN_V, OPT_CONV_TFAST, OPT_CONV_SPLIT, OPT_ATTN5_V, OPT_HALO_PREF, OPT_EPI_PREF, OPT_COUNT };
 int opt(Opt o, int dflt);
 // hipFuncSetAttribute is a per-device setting, done once per (call site, device): attr_pending returns the device's bit
 // while the attribute is not set yet (0 afterwards); attr_done publishes it once the call has succeeded

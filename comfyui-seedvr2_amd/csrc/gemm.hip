@@ -351,9 +351,10 @@ int launch(const KArgs& a, hipStream_t s) {
 namespace svr2 {
 static const char* const kOptNames[OPT_COUNT] = {"SVR2_HALO_WR", "SVR2_GEMM_V", "SVR2_GEMM4", "SVR2_GEMM_BM",
                                                  "SVR2_GEMM2_NARROW", "SVR2_CONV_LINEAR_TILES", "SVR2_ATTN_V",
-                                                 "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT", "SVR2_ATTN5_V", "SVR2_HALO_PREF"};
+                                                 "SVR2_CONV_TFAST", "SVR2_CONV_SPLIT", "SVR2_ATTN5_V", "SVR2_HALO_PREF",
+                                                 "SVR2_EPI_PREF"};
 static const int kUnset = INT32_MIN;
-static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}, {kUnset}};
 static const int kDefault = INT32_MIN + 1;   // "resolved: neither set nor in the environment"
 
 int opt(Opt o, int dflt) {
@@ -441,6 +442,7 @@ extern "C" int svr2_gemm(const svr2_gemm_desc* d, void* stream) {
         case SVR2_EPI_GATE_RES:
             SVR2_CHECK(d->resid && d->ldr % 8 == 0 && aligned16(d->resid) && d->N % 8 == 0, SVR2_E_ARG,
                        "svr2_gemm: GATE_RES needs resid (16B aligned, ldr %% 8 == 0) and N %% 8 == 0");
+            a.epi_pref = svr2::opt(svr2::OPT_EPI_PREF, 1);      // SVR2_EPI_PREF=0: residual loaded chunk by chunk (A/B; same bits)
             return launch<A_DENSE, SVR2_EPI_GATE_RES>(a, s);
         case SVR2_EPI_SWIGLU:
             SVR2_CHECK(d->N % 16 == 0 && d->bias == nullptr, SVR2_E_SHAPE,

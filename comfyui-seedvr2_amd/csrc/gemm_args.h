@@ -51,6 +51,7 @@ struct KArgs {
     int M, N, K, nbm, nbn;
     int ps_frames, ps_h, ps_w, ps_c, ps_tz, ps_drop;
     FastDiv ps_wd, ps_hd, ps_cd;   // divisors ps_w, ps_h, ps_c
+    int epi_pref;                  // GATE_RES epilogue: request every residual chunk before the first one is used
     ConvGeom cg;
 };
 
@@ -129,6 +130,40 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& a, const char* smem, 
         return;
     }
 
+    if (EPI == SVR2_EPI_GATE_RES && a.epi_pref) {
+        // resid + gate x tile: a thread's 16-byte residual chunks are all requested first - one exposed HBM round trip per
+        // tile instead of one per chunk (the loop below waits for its load in every iteration; this workgroup is alone on
+        // its CU, so nothing else covers that wait: -9 % on the K = 2 560 projection at M = 194 400)
+        constexpr int CH = BM * (BN / 8) / NT;
+        static_assert(BM * (BN / 8) % NT == 0 && NT % (BN / 8) == 0, "whole chunks per thread, one column group per thread");
+        const int cc = tid % (BN / 8), n = n0 + cc * 8;
+        bf16x8 rres[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int m = tile_row_to_m<AMODE, BM>(a, tm, (tid + k * NT) / (BN / 8));
+            rres[k] = (m < a.M && n < a.N) ? *(const bf16x8*)(a.resid + (long long)m * a.ldr + n) : bf16x8{};
+        }
+        float g8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g8[e] = (a.gate && n + e < a.N) ? a.gate[n + e] : 1.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int row = (tid + k * NT) / (BN / 8);
+            const int m = tile_row_to_m<AMODE, BM>(a, tm, row);
+            if (m >= a.M || n >= a.N) continue;
+            const bf16x8 tv = *(const bf16x8*)(smem + row * EPI_LD + cc * 16);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rres[k][e]) + g8[e] * bf2f(tv[e]));
+            const long long dst = (long long)m * a.ldc + n;
+            if (n + 8 <= a.N) {
+                *(bf16x8*)(a.C + dst) = o;
+            } else {
+                for (int e = 0; e < a.N - n; ++e) a.C[dst + e] = o[e];
+            }
+        }
+        return;
+    }
     for (int c = tid; c < BM * (BN / 8); c += NT) {
         const int row = c / (BN / 8), cc = c % (BN / 8);
         const int m = tile_row_to_m<AMODE, BM>(a, tm, row), n = n0 + cc * 8;

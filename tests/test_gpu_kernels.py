@@ -91,6 +91,24 @@ def test_gemm4_pingpong_epilogues(pkg, gpu, lib_option):
     assert_close(out, F.gelu(a[:M] @ w.T + b2, approximate="tanh"), "gemm4 gelu")
 
 
+@pytest.mark.parametrize("M,N,K,ver", [(1500, 2560, 1024, 2), (700, 512, 256, 3), (3000, 256, 192, 2), (1024, 2560, 2560, 2)])
+def test_gemm_gate_res_prefetched_epilogue_is_bit_identical(pkg, gpu, M, N, K, ver, lib_option):
+    """gemm2 / gemm4's gated-residual epilogue requests every residual chunk of a thread before the first one is used
+    (default); SVR2_EPI_PREF=0 loads them chunk by chunk: the same arithmetic, the same bits (ragged last row tile and the
+    128-row kernel, which has its own epilogue, included).  [ref: modulation.py AdaSingle 'out' + residual, mmattn.py:269]"""
+    hip = pkg.hip
+    lib_option("SVR2_GEMM_V", ver)
+    a, w = dev_bf16(rnd(M, K, seed=91), gpu), hip.pad_weight(rnd(N, K, seed=92, scale=1 / math.sqrt(K)).to(gpu))
+    bias, gate, res = rnd(N, seed=93).to(gpu), rnd(N, seed=94).to(gpu), dev_bf16(rnd(M, N, seed=95), gpu)
+    run = lambda: hip.gemm(a, w, N, epilogue=hip.EPI_GATE_RES, bias=bias, gate=gate, resid=res, m=M)
+    got = run()
+    lib_option("SVR2_EPI_PREF", 0)
+    want = run()
+    assert torch.equal(got, want)
+    ref = res.float().cpu() + gate.cpu() * (a.float().cpu() @ w[:N].float().cpu().T + bias.cpu())
+    assert_close(got, ref, f"gate_res {M}x{N}x{K}")
+
+
 def test_gemm_gather_gate_res(pkg, gpu):
     hip = pkg.hip
     M, N, K, S = 700, 256, 256, 900

@@ -183,7 +183,7 @@ if __name__ == "__main__":
         if os.environ.get("SVR2_KB_SHAPES"):     # name:M:N:K:epi,...
             shapes = [(f[0], int(f[1]), int(f[2]), int(f[3]), f[4]) for f in
                       (t.split(":") for t in os.environ["SVR2_KB_SHAPES"].split(","))]
-        settings = [("default", {}), ("bm256", {"SVR2_GEMM_BM": 256}), ("gemm4", {"SVR2_GEMM_V": 3}),
+        settings = [("default", {}), ("no residual prefetch", {"SVR2_EPI_PREF": 0}), ("bm256", {"SVR2_GEMM_BM": 256}), ("gemm4", {"SVR2_GEMM_V": 3}),
                     ("bm128_2deep", {"SVR2_GEMM_BM": 128, "SVR2_GEMM_V": 1}),
                     ("gemm2_256x256", {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0}),
                     ("gemm2_256x128", {"SVR2_GEMM_V": 3, "SVR2_GEMM4": 0, "SVR2_GEMM2_NARROW": 1})]
@@ -318,6 +318,15 @@ if __name__ == "__main__":
                                               w_layout=hip.WL_TILED_128x32, gn_stats=True), iters=20, warm=3)
                 print(f"conv {H}x{W} 512->512 ({tiles} tiles) SVR2_CONV_SPLIT={mode}: {t*1e6:.0f} us  {fl/t/1e12:.0f} TFLOP/s", flush=True)
             hip.set_option("SVR2_CONV_SPLIT", None)
+    if "gateres" in which:   # the two gated-residual projections of a NaDiT-3B layer at the 4K batch size (gemm4), A/B of the
+        # residual prefetch in the epilogue; then the NaDiT-7B pair
+        for (M, N, K_) in ((194400, 2560, 2560), (194400, 2560, 6912), (194400, 3072, 3072), (194400, 3072, 12288)):
+            for r in range(2):
+                for mode in (0, 1):
+                    hip.set_option("SVR2_EPI_PREF", mode)
+                    print(f"SVR2_EPI_PREF={mode}: ", end="")
+                    bench_gemm(M, N, K_, "gate")
+            hip.set_option("SVR2_EPI_PREF", None)
     if "attn4k" in which:   # the 4K window set (T=21 -> latent grid (6,135,240)), NaDiT-3B heads; then the 7B head count
         vers = tuple(int(x) for x in os.environ.get("SVR2_KB_ATTN_VERS", "1,5").split(","))
         bench_attn_ab((6, 135, 240), 20, vers)
