@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2     # SVR2_ABI_VERSION of include/seedvr2_hip.h this binding was written against (struct layouts below)
 LIB_PATH = os.environ.get("SVR2_LIB") or os.path.join(_HERE, "libseedvr2_hip.so")  # SVR2_LIB: A/B builds
 
 EPI_BIAS, EPI_GATE_RES, EPI_SWIGLU, EPI_PIXSHUF3D, EPI_GELU = 0, 1, 2, 3, 4
@@ -102,6 +103,12 @@ def lib() -> C.CDLL:
             import sys
             print(f"[seedvr2_amd] loading the HIP library from SVR2_LIB={LIB_PATH}", file=sys.stderr, flush=True)
         _lib = C.CDLL(LIB_PATH)
+        _lib.svr2_abi_version.restype = C.c_int
+        got = _lib.svr2_abi_version()
+        if got != ABI_VERSION:     # descriptor layouts are version-bound: a stale library would read them wrongly, silently
+            _lib = None
+            raise HipError(f"{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(`python __graft_entry__.py`)")
         _lib.svr2_last_error.restype = C.c_char_p
         for name in EXPORTS:
             if name != "svr2_last_error" and hasattr(_lib, name):

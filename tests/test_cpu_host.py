@@ -164,6 +164,8 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.hip.EXPORTS) == declared
     lib.svr2_abi_version.restype = ctypes.c_int
     assert lib.svr2_abi_version() == 2
+    # header, library and binding agree on the version the descriptor layouts belong to (hip.lib() refuses a mismatch)
+    assert int(re.search(r"#define SVR2_ABI_VERSION (\d+)", hdr).group(1)) == pkg.hip.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu(pkg):
